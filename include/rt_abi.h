@@ -1,0 +1,225 @@
+/* rt_abi.h - C ABI of the MI355X (gfx950) path-tracing library, librt_hip.so.
+ *
+ * This is the drop-in boundary for the reference's CPU tile renderer (Nanoteck137/ray_tracing,
+ * src/cpu).  A host that owns the reference's scene / camera / tile types fills the POD mirrors
+ * below and calls rt_render() where it used to call dispatch_work_cpu_multithreaded(), or
+ * rt_render_tiles() where it used to loop execute_job() over its tile queue.  No type from any
+ * framework appears in a signature: plain pointers, sizes and integers only.
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative rt_status on failure; the message is
+ *    available from rt_last_error() (thread-local).  Nothing aborts and nothing throws.
+ *  - the caller owns every buffer it passes; the library keeps no pointer after a call returns
+ *    (rt_scene objects own their own device copies).
+ *  - calls are blocking unless the name ends in _async; one host thread at a time per process.
+ *  - results are a pure function of (seed, scene, camera, W, H, spp, max_depth, flags): they do
+ *    not depend on tiling, on launch geometry or on how many GPUs share the frame.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID_ARGUMENT = -1,
+  RT_ERR_NOT_INITIALIZED = -2,
+  RT_ERR_DEVICE = -3,        /* a HIP call failed; rt_last_error() names it */
+  RT_ERR_OUT_OF_MEMORY = -4,
+  RT_ERR_LIMIT = -5          /* a documented size limit was exceeded */
+} rt_status;
+
+/* Mirror of `struct Sphere { position: Vec3, radius: f32, material_id: usize }`
+ * (reference src/main.rs:119-125).  20 bytes, no padding. */
+typedef struct rt_sphere {
+  float x, y, z;
+  float radius;
+  uint32_t material_id;
+} rt_sphere;
+
+/* Mirror of `struct Material { color, metallic, metallic_strength, dielectric, ir }`
+ * (reference src/main.rs:108-117).  The two bools travel as bits of `flags`.
+ * Shading precedence is dielectric > metallic > diffuse (src/main.rs:201,228,243). */
+#define RT_MAT_METALLIC 1u
+#define RT_MAT_DIELECTRIC 2u
+typedef struct rt_material {
+  float r, g, b;
+  uint32_t flags;
+  float metallic_strength;
+  float ir;
+} rt_material;
+
+/* Mirror of `struct Camera { view_matrix_inv: Mat4, projection_matrix_inv: Mat4 }`
+ * (reference src/main.rs:51-55): two column-major 4x4 f32, the order of glam's to_cols_array(). */
+typedef struct rt_camera {
+  float view_inv[16];
+  float proj_inv[16];
+} rt_camera;
+
+/* Mirror of `struct TileJob { x, y, width, height }` (reference src/cpu/job.rs:6-13). */
+typedef struct rt_tile {
+  uint32_t x, y, width, height;
+} rt_tile;
+
+/* Request flags */
+#define RT_FLAG_STRICT_FP 1u      /* evaluate the ray/sphere discriminant in the reference's exact
+                                     operation order with no fused multiply-add (slower; every
+                                     hit decision is then bit-identical to the CPU oracle) */
+#define RT_FLAG_SEQUENTIAL_SUM 2u /* never split one pixel's samples over several lanes: the
+                                     per-pixel sum is then formed in sample order, exactly like
+                                     `pixel_color += color` in src/cpu/job.rs:58 */
+
+/* Mirror of `struct Dispatch` (reference src/cpu/mod.rs:19-30) plus the render seed.
+ * `tiles` may be NULL for rt_render() (the GPU path does not need the caller's tiling);
+ * rt_render_tiles() requires it. */
+typedef struct rt_request {
+  uint32_t image_width;
+  uint32_t image_height;
+  uint32_t max_depth;
+  uint32_t samples_per_pixel;
+  uint32_t seed;
+  uint32_t flags;
+  rt_camera camera;
+  const rt_sphere* spheres;
+  uint32_t n_spheres;
+  const rt_material* materials;
+  uint32_t n_materials;
+  const rt_tile* tiles;
+  uint32_t n_tiles;
+} rt_request;
+
+/* Counters of the most recent render on this process's device. */
+typedef struct rt_stats {
+  uint64_t rays;        /* World::hit calls (one per path segment), src/main.rs:196 */
+  uint64_t samples;     /* shoot_ray calls from the pixel loop, src/cpu/job.rs:57 */
+  uint64_t sphere_tests; /* rays * n_spheres */
+  float kernel_ms;      /* device time of the path-tracing kernel (HIP events on its stream) */
+  uint32_t rays_per_lane;
+  uint32_t slices;      /* lanes that shared one pixel's samples (1 = sequential sum) */
+  uint32_t workgroups;
+  uint32_t threads_per_workgroup;
+} rt_stats;
+
+/* Opaque device-resident scene (sphere geometry, per-sphere material ids, materials). */
+typedef struct rt_scene rt_scene;
+
+/* Parameters of a device-level render: everything in rt_request that is not a pointer. */
+typedef struct rt_frame {
+  uint32_t image_width;
+  uint32_t image_height;
+  uint32_t max_depth;
+  uint32_t samples_per_pixel;
+  uint32_t seed;
+  uint32_t flags;
+  rt_camera camera;
+} rt_frame;
+
+/* One record of the per-ray test hook. */
+typedef struct rt_ray_in {
+  float ox, oy, oz;
+  float dx, dy, dz;
+} rt_ray_in;
+
+#define RT_KIND_MISS 0u
+#define RT_KIND_DIFFUSE 1u
+#define RT_KIND_METAL 2u
+#define RT_KIND_DIELECTRIC 3u
+typedef struct rt_ray_out {
+  uint32_t hit;          /* 0 = miss (then sky[] holds the background colour) */
+  uint32_t sphere;       /* index of the closest sphere */
+  uint32_t material;
+  uint32_t kind;         /* RT_KIND_* */
+  uint32_t front_face;
+  uint32_t scattered;    /* 0 when the path ends here (miss, or absorbed metal reflection) */
+  uint32_t draws;        /* random numbers consumed by this bounce */
+  float t;
+  float px, py, pz;      /* hit point */
+  float nx, ny, nz;      /* face normal */
+  float sx, sy, sz;      /* scattered direction (not normalised, as in the reference) */
+  float ar, ag, ab;      /* factor applied to the radiance returned by the next segment */
+} rt_ray_out;
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+
+/* Select `device` (HIP ordinal) for this process, create the stream and the work counters.
+ * Replaces nothing in the reference (its renderer needs no set-up); it is the FFI's one-time
+ * initialisation.  Calling it again with the same device is a no-op. */
+int rt_init(int device);
+int rt_shutdown(void);
+const char* rt_last_error(void);
+int rt_abi_version(void);
+
+/* ---- drop-in entry points (host pointers in, host pointers out) -------------------------- */
+
+/* Replaces cpu::dispatch_work_cpu_multithreaded(dispatch, n) and
+ * cpu::dispatch_work_cpu_singlethreaded(dispatch) (reference src/cpu/multi.rs:131-172,
+ * src/cpu/single.rs:10-50) including their call of compose_final_framebuffer
+ * (src/cpu/mod.rs:51-83).  out_rgb receives image_width*image_height RGB triples, row-major,
+ * fb[x + y*W], y = 0 at the bottom, each channel clamp(sqrt(sum/spp), 0, 0.999). */
+int rt_render(const rt_request* req, float* out_rgb);
+
+/* Replaces the loop `for job in queue { execute_job(&job, &data) }` (reference
+ * src/cpu/job.rs:36-74 as driven by src/cpu/single.rs:17-39 / src/cpu/multi.rs:30-62).
+ * out_sums receives, tile after tile in the order of req->tiles, width*height RGB triples per
+ * tile, row-major inside the tile: the UN-NORMALISED sums of JobResult.pixel_colors. */
+int rt_render_tiles(const rt_request* req, float* out_sums);
+
+/* Replaces compose_final_framebuffer (reference src/cpu/mod.rs:51-83) for callers that kept the
+ * per-tile sums: scatters the tiles into out_rgb (W*H*3) applying x*(1/spp), sqrt, clamp. */
+int rt_compose(const rt_tile* tiles, uint32_t n_tiles, const float* tile_sums,
+               uint32_t image_width, uint32_t image_height, uint32_t samples_per_pixel,
+               float* out_rgb);
+
+/* ---- device-resident entry points (for callers that keep the frame in HBM) --------------- */
+
+/* Upload a World (reference src/main.rs:168-172).  The reference keeps its world in host
+ * vectors shared by the workers (src/cpu/multi.rs:143); this is the device copy. */
+int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres,
+                    const rt_material* materials, uint32_t n_materials, rt_scene** out_scene);
+int rt_scene_destroy(rt_scene* scene);
+
+/* execute_job over a set of tiles with the output left in device memory.
+ *   d_out      device pointer; pixel (px,py) of tile i goes to
+ *              d_out[3 * (out_offset[i] + (py - tile.y) * out_stride[i] + (px - tile.x))]
+ *   resolve    0: un-normalised sums (JobResult contract); 1: compose_final_framebuffer's
+ *              x*(1/spp), sqrt, clamp applied on the way out
+ *   stream     a hipStream_t passed as void*, or NULL for the library's own stream
+ * Enqueues the work and returns; rt_synchronize() or the caller's own stream sync completes it.
+ * Same reference counterpart as rt_render_tiles. */
+int rt_render_device_async(const rt_scene* scene, const rt_frame* frame,
+                           const rt_tile* tiles, const uint64_t* out_offset,
+                           const uint32_t* out_stride, uint32_t n_tiles,
+                           int resolve, float* d_out, void* stream);
+
+/* Convenience form of the above for one horizontal band of full-width rows
+ * [row_begin, row_end): d_out holds (row_end-row_begin)*W RGB triples, row-major.  This is the
+ * unit a multi-GPU host gives each rank (rows shard like the reference's tiles do over
+ * threads, src/cpu/multi.rs:30-62). */
+int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame,
+                                uint32_t row_begin, uint32_t row_end,
+                                int resolve, float* d_out, void* stream);
+
+int rt_synchronize(void* stream);
+int rt_get_stats(rt_stats* out);
+
+/* ---- test hook --------------------------------------------------------------------------- */
+
+/* One World::hit + one scatter decision per input ray (reference src/main.rs:175-189 and the
+ * body of shoot_ray, src/main.rs:196-251), with ray i drawing its random numbers from the
+ * stream rt_rng_init(seed, i, 0) of rt_rng.h.  Exists so that hit distance, normal and
+ * scatter direction can be compared ray by ray with the CPU oracle. */
+int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays,
+                  uint32_t seed, uint32_t flags, rt_ray_out* out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_ABI_H */
