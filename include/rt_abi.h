@@ -209,6 +209,13 @@ int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame,
 int rt_synchronize(void* stream);
 int rt_get_stats(rt_stats* out);
 
+/* Device time, in milliseconds, of each of the last `n_last` path-tracing kernel launches
+ * (oldest first), measured with HIP events recorded on the stream each launch ran on.  At most
+ * the 64 most recent launches are kept.  Waits for those launches to finish.  Returns the
+ * number of values written, or a negative rt_status.  The counterpart in the reference is the
+ * Instant::now()/elapsed() pair around the tile loop (src/cpu/multi.rs:146,163). */
+int rt_get_launch_ms(uint32_t n_last, float* out_ms);
+
 /* ---- test hook --------------------------------------------------------------------------- */
 
 /* One World::hit + one scatter decision per input ray (reference src/main.rs:175-189 and the

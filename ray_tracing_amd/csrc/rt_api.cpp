@@ -1,0 +1,568 @@
+// rt_api.cpp - host side of librt_hip.so: the C ABI declared in include/rt_abi.h.
+//
+// Everything here is plumbing around the kernels of rt_kernels.hip: argument checks, the
+// device copy of the World, the tile table, launch geometry, and the two host-pointer entry
+// points that stand in for the reference's dispatch_work_cpu_* (src/cpu/multi.rs:131-172,
+// src/cpu/single.rs:10-50).  There is no CPU rendering path in this library: without a GPU
+// every compute entry point fails with RT_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_rng.h"
+#include "rt_internal.h"
+
+struct rt_scene {
+  rt::SceneDev dev;
+  void* geom = nullptr;
+  void* aux = nullptr;
+  void* mat = nullptr;
+  int device = -1;
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define RT_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE,       \
+                  "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+constexpr int kEventRing = 64;
+
+struct State {
+  bool ready = false;
+  int device = -1;
+  int cus = 0;
+  hipStream_t stream = nullptr;
+  rt::Counters* counters = nullptr;       // device
+  rt::TileDev* tiles = nullptr;           // device, grow-only
+  size_t tiles_cap = 0;
+  float* partial = nullptr;               // device, grow-only: per-slice sums
+  size_t partial_cap = 0;                 // in floats
+  hipEvent_t ev_begin[kEventRing], ev_end[kEventRing];
+  uint64_t launches = 0;
+  rt_stats last = {};
+  hipStream_t last_stream = nullptr;
+};
+State g;
+
+int check_ready() {
+  if (!g.ready) return fail(RT_ERR_NOT_INITIALIZED, "rt_init() has not been called");
+  return RT_OK;
+}
+
+int check_frame(const rt_frame* f) {
+  if (!f) return fail(RT_ERR_INVALID_ARGUMENT, "frame is NULL");
+  if (f->image_width == 0 || f->image_height == 0)
+    return fail(RT_ERR_INVALID_ARGUMENT, "image is %ux%u", f->image_width, f->image_height);
+  if (f->samples_per_pixel == 0) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel is 0");
+  if ((uint64_t)f->image_width * f->image_height > 0x7FFFFFFFull)
+    return fail(RT_ERR_LIMIT, "more than 2^31 pixels");
+  if (f->flags & ~(RT_FLAG_STRICT_FP | RT_FLAG_SEQUENTIAL_SUM))
+    return fail(RT_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", f->flags);
+  return RT_OK;
+}
+
+// Lanes that share one pixel's samples.  A function of the FULL image and spp only, so a
+// frame gives the same sums whatever part of it a call renders.
+uint32_t choose_slices(const rt_frame& f) {
+  if (f.flags & RT_FLAG_SEQUENTIAL_SUM) return 1;
+  const uint64_t pixels = (uint64_t)f.image_width * f.image_height;
+  if (pixels >= rt::kTargetItems) return 1;
+  uint64_t s = (rt::kTargetItems + pixels - 1) / pixels;
+  if (s > f.samples_per_pixel) s = f.samples_per_pixel;
+  if (s > 64) s = 64;
+  return (uint32_t)s;
+}
+
+int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
+                        const std::vector<rt::TileDev>& tiles, uint64_t out_pixels, int resolve,
+                        float* d_out, hipStream_t stream) {
+  rt::TraceParams p;
+  memset(&p, 0, sizeof p);
+  p.scene = scene->dev;
+  p.cam = frame->camera;
+  // origin = view_inv * (0,0,0,1) in glam's order ((c0*x + c1*y) + c2*z) + c3*w
+  for (int i = 0; i < 3; ++i) {
+    const float* V = frame->camera.view_inv;
+    volatile float r = V[i] * 0.0f;
+    r = r + V[4 + i] * 0.0f;
+    r = r + V[8 + i] * 0.0f;
+    r = r + V[12 + i] * 1.0f;
+    p.origin[i] = r;
+  }
+  p.width = frame->image_width;
+  p.height = frame->image_height;
+  p.max_depth = frame->max_depth;
+  p.spp = frame->samples_per_pixel;
+  p.seed_a = rt_rng_seed_a(frame->seed);
+  p.seed_b = rt_rng_seed_b(frame->seed);
+  p.slices = choose_slices(*frame);
+  p.n_tiles = (uint32_t)tiles.size();
+  uint64_t total_pixels = 0;
+  for (const rt::TileDev& t : tiles) total_pixels += (uint64_t)t.w * t.h;
+  if (total_pixels == 0) return RT_OK;
+  if (total_pixels * p.slices >= 0xFFFFFF00ull || out_pixels * p.slices >= 0xFFFFFF00ull)
+    return fail(RT_ERR_LIMIT, "more than 2^32 work items in one call");
+  p.total_pixels = (uint32_t)total_pixels;
+  p.total_items = (uint32_t)(total_pixels * p.slices);
+  p.out_pixels = out_pixels;
+  p.inv_spp = 1.0f / (float)frame->samples_per_pixel;   // `1.0 / spp as f32`, src/cpu/mod.rs:67
+  p.counters = g.counters;
+
+  const bool strict = (frame->flags & RT_FLAG_STRICT_FP) != 0;
+
+  if (frame->max_depth == 0) {
+    // shoot_ray(ray, 0) is black (src/main.rs:192-194): every sum is 0 and nothing is traced
+    RT_HIP(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(float), stream));
+    g.last = {};
+    g.last.samples = total_pixels * frame->samples_per_pixel;
+    g.last_stream = stream;
+    return RT_OK;
+  }
+
+  if (tiles.size() == 1) {
+    p.tile0 = tiles[0];
+    p.tiles = nullptr;
+  } else {
+    if (tiles.size() > g.tiles_cap) {
+      RT_HIP(hipStreamSynchronize(stream));
+      if (g.tiles) RT_HIP(hipFree(g.tiles));
+      g.tiles = nullptr;
+      g.tiles_cap = 0;
+      RT_HIP(hipMalloc((void**)&g.tiles, tiles.size() * sizeof(rt::TileDev)));
+      g.tiles_cap = tiles.size();
+    }
+    // the previous launch may still be reading the table
+    RT_HIP(hipStreamSynchronize(stream));
+    RT_HIP(hipMemcpy(g.tiles, tiles.data(), tiles.size() * sizeof(rt::TileDev),
+                     hipMemcpyHostToDevice));
+    p.tiles = g.tiles;
+  }
+
+  float* trace_out = d_out;
+  if (p.slices > 1) {
+    const size_t need = (size_t)out_pixels * 3 * p.slices;
+    if (need > g.partial_cap) {
+      RT_HIP(hipStreamSynchronize(stream));
+      if (g.partial) RT_HIP(hipFree(g.partial));
+      g.partial = nullptr;
+      g.partial_cap = 0;
+      RT_HIP(hipMalloc((void**)&g.partial, need * sizeof(float)));
+      g.partial_cap = need;
+    }
+    // tiles need not cover the output: pixels no tile writes must read as 0 in every slice
+    RT_HIP(hipMemsetAsync(g.partial, 0, need * sizeof(float), stream));
+    trace_out = g.partial;
+    p.resolve = 0;
+  } else {
+    p.resolve = resolve;
+  }
+  p.out = trace_out;
+
+  const size_t lds = rt::trace_lds_bytes(scene->dev.n_spheres);
+  const bool multi = scene->dev.n_spheres > rt::kChunkSpheres;
+  int per_cu = 0;
+  RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, lds, &per_cu));
+  if (per_cu < 1) return fail(RT_ERR_DEVICE, "trace kernel does not fit on a CU (LDS %zu B)", lds);
+  int blocks = per_cu * g.cus;
+  const uint64_t lanes_needed = ((uint64_t)p.total_items + rt::kRaysPerLane - 1) / rt::kRaysPerLane;
+  const uint64_t blocks_needed = (lanes_needed + rt::kThreads - 1) / rt::kThreads;
+  if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
+  if (blocks < 1) blocks = 1;
+
+  RT_HIP(hipMemsetAsync(g.counters, 0, sizeof(rt::Counters), stream));
+  const int slot = (int)(g.launches % kEventRing);
+  RT_HIP(hipEventRecord(g.ev_begin[slot], stream));
+  RT_HIP(rt::launch_trace(p, strict, blocks, stream));
+  RT_HIP(hipEventRecord(g.ev_end[slot], stream));
+  g.launches++;
+
+  if (p.slices > 1) {
+    rt::ReduceParams rp;
+    rp.partial = g.partial;
+    rp.out = d_out;
+    rp.out_pixels = out_pixels;
+    rp.slices = p.slices;
+    rp.resolve = resolve;
+    rp.inv_spp = p.inv_spp;
+    RT_HIP(rt::launch_reduce(rp, stream));
+  }
+
+  g.last = {};
+  g.last.rays_per_lane = rt::kRaysPerLane;
+  g.last.slices = p.slices;
+  g.last.workgroups = (uint32_t)blocks;
+  g.last.threads_per_workgroup = rt::kThreads;
+  g.last.sphere_tests = scene->dev.n_spheres;   // multiplied by rays in rt_get_stats
+  g.last_stream = stream;
+  return RT_OK;
+}
+
+int check_request(const rt_request* req, bool need_tiles) {
+  if (!req) return fail(RT_ERR_INVALID_ARGUMENT, "request is NULL");
+  if (req->n_spheres && !req->spheres) return fail(RT_ERR_INVALID_ARGUMENT, "spheres is NULL");
+  if (req->n_materials && !req->materials) return fail(RT_ERR_INVALID_ARGUMENT, "materials is NULL");
+  if (need_tiles && req->n_tiles && !req->tiles) return fail(RT_ERR_INVALID_ARGUMENT, "tiles is NULL");
+  return RT_OK;
+}
+
+rt_frame frame_of(const rt_request* req) {
+  rt_frame f;
+  f.image_width = req->image_width;
+  f.image_height = req->image_height;
+  f.max_depth = req->max_depth;
+  f.samples_per_pixel = req->samples_per_pixel;
+  f.seed = req->seed;
+  f.flags = req->flags;
+  f.camera = req->camera;
+  return f;
+}
+
+int check_tiles(const rt_tile* tiles, uint32_t n, uint32_t w, uint32_t h) {
+  for (uint32_t i = 0; i < n; ++i) {
+    const rt_tile& t = tiles[i];
+    if ((uint64_t)t.x + t.width > w || (uint64_t)t.y + t.height > h)
+      return fail(RT_ERR_INVALID_ARGUMENT, "tile %u (%u,%u %ux%u) leaves the %ux%u image", i, t.x,
+                  t.y, t.width, t.height, w, h);
+  }
+  return RT_OK;
+}
+
+struct ScopedScene {
+  rt_scene* s = nullptr;
+  ~ScopedScene() { if (s) rt_scene_destroy(s); }
+};
+struct ScopedDev {
+  void* p = nullptr;
+  ~ScopedDev() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+int rt_init(int device) {
+  if (g.ready) {
+    if (g.device == device) return RT_OK;
+    return fail(RT_ERR_INVALID_ARGUMENT, "already initialised on device %d", g.device);
+  }
+  int count = 0;
+  RT_HIP(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count)
+    return fail(RT_ERR_INVALID_ARGUMENT, "device %d of %d", device, count);
+  RT_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  RT_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RT_ERR_DEVICE, "device %d is %s; this library holds gfx950 code only", device,
+                prop.gcnArchName);
+  g.cus = prop.multiProcessorCount;
+  RT_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  RT_HIP(hipMalloc((void**)&g.counters, sizeof(rt::Counters)));
+  RT_HIP(hipMemset(g.counters, 0, sizeof(rt::Counters)));
+  for (int i = 0; i < kEventRing; ++i) {
+    RT_HIP(hipEventCreate(&g.ev_begin[i]));
+    RT_HIP(hipEventCreate(&g.ev_end[i]));
+  }
+  g.device = device;
+  g.launches = 0;
+  g.ready = true;
+  return RT_OK;
+}
+
+int rt_shutdown(void) {
+  if (!g.ready) return RT_OK;
+  (void)hipSetDevice(g.device);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < kEventRing; ++i) {
+    (void)hipEventDestroy(g.ev_begin[i]);
+    (void)hipEventDestroy(g.ev_end[i]);
+  }
+  if (g.counters) (void)hipFree(g.counters);
+  if (g.tiles) (void)hipFree(g.tiles);
+  if (g.partial) (void)hipFree(g.partial);
+  if (g.stream) (void)hipStreamDestroy(g.stream);
+  g = State();
+  return RT_OK;
+}
+
+int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_material* materials,
+                    uint32_t n_materials, rt_scene** out_scene) {
+  if (int rc = check_ready()) return rc;
+  if (!out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "out_scene is NULL");
+  *out_scene = nullptr;
+  if ((n_spheres && !spheres) || (n_materials && !materials))
+    return fail(RT_ERR_INVALID_ARGUMENT, "NULL scene arrays");
+  if (n_spheres > (1u << 24)) return fail(RT_ERR_LIMIT, "more than 2^24 spheres");
+  for (uint32_t i = 0; i < n_spheres; ++i)
+    if (spheres[i].material_id >= n_materials)
+      return fail(RT_ERR_INVALID_ARGUMENT, "sphere %u names material %u of %u", i,
+                  spheres[i].material_id, n_materials);
+  RT_HIP(hipSetDevice(g.device));
+
+  std::vector<float4> geom(n_spheres ? n_spheres : 1);
+  std::vector<float2> aux(n_spheres ? n_spheres : 1);
+  std::vector<float4> mat(n_materials ? 2 * (size_t)n_materials : 2);
+  for (uint32_t i = 0; i < n_spheres; ++i) {
+    const rt_sphere& s = spheres[i];
+    volatile float r2 = s.radius * s.radius;   // `self.radius * self.radius`, src/main.rs:134
+    geom[i] = make_float4(s.x, s.y, s.z, r2);
+    float idbits;
+    memcpy(&idbits, &s.material_id, sizeof idbits);
+    aux[i] = make_float2(s.radius, idbits);
+  }
+  for (uint32_t m = 0; m < n_materials; ++m) {
+    float flagbits;
+    memcpy(&flagbits, &materials[m].flags, sizeof flagbits);
+    mat[2 * m] = make_float4(materials[m].r, materials[m].g, materials[m].b, flagbits);
+    mat[2 * m + 1] = make_float4(materials[m].metallic_strength, materials[m].ir, 0.0f, 0.0f);
+  }
+  rt_scene* s = new rt_scene();
+  s->device = g.device;
+  ScopedScene guard;
+  guard.s = s;
+  RT_HIP(hipMalloc(&s->geom, geom.size() * sizeof(float4)));
+  RT_HIP(hipMalloc(&s->aux, aux.size() * sizeof(float2)));
+  RT_HIP(hipMalloc(&s->mat, mat.size() * sizeof(float4)));
+  RT_HIP(hipMemcpy(s->geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(s->aux, aux.data(), aux.size() * sizeof(float2), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(s->mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
+  s->dev.geom = (const float4*)s->geom;
+  s->dev.aux = (const float2*)s->aux;
+  s->dev.mat = (const float4*)s->mat;
+  s->dev.n_spheres = n_spheres;
+  s->dev.n_materials = n_materials;
+  guard.s = nullptr;
+  *out_scene = s;
+  return RT_OK;
+}
+
+int rt_scene_destroy(rt_scene* scene) {
+  if (!scene) return RT_OK;
+  if (scene->geom) (void)hipFree(scene->geom);
+  if (scene->aux) (void)hipFree(scene->aux);
+  if (scene->mat) (void)hipFree(scene->mat);
+  delete scene;
+  return RT_OK;
+}
+
+int rt_render_device_async(const rt_scene* scene, const rt_frame* frame, const rt_tile* tiles,
+                           const uint64_t* out_offset, const uint32_t* out_stride,
+                           uint32_t n_tiles, int resolve, float* d_out, void* stream) {
+  if (int rc = check_ready()) return rc;
+  if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  if (int rc = check_frame(frame)) return rc;
+  if (n_tiles == 0) return RT_OK;
+  if (!tiles || !out_offset || !out_stride || !d_out)
+    return fail(RT_ERR_INVALID_ARGUMENT, "NULL tile table or output");
+  if (int rc = check_tiles(tiles, n_tiles, frame->image_width, frame->image_height)) return rc;
+  std::vector<rt::TileDev> td;
+  td.reserve(n_tiles);
+  uint64_t first = 0, out_pixels = 0;
+  for (uint32_t i = 0; i < n_tiles; ++i) {
+    if (tiles[i].width == 0 || tiles[i].height == 0) continue;
+    if (out_stride[i] < tiles[i].width)
+      return fail(RT_ERR_INVALID_ARGUMENT, "tile %u: out_stride %u < width %u", i, out_stride[i],
+                  tiles[i].width);
+    rt::TileDev t;
+    t.x = tiles[i].x; t.y = tiles[i].y; t.w = tiles[i].width; t.h = tiles[i].height;
+    t.first_pixel = (uint32_t)first;
+    t.out_stride = out_stride[i];
+    t.out_offset = out_offset[i];
+    first += (uint64_t)t.w * t.h;
+    const uint64_t end = t.out_offset + (uint64_t)(t.h - 1) * t.out_stride + t.w;
+    if (end > out_pixels) out_pixels = end;
+    td.push_back(t);
+  }
+  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  return render_tiles_device(scene, frame, td, out_pixels, resolve, d_out, s);
+}
+
+int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame, uint32_t row_begin,
+                                uint32_t row_end, int resolve, float* d_out, void* stream) {
+  if (int rc = check_ready()) return rc;
+  if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  if (int rc = check_frame(frame)) return rc;
+  if (row_begin > row_end || row_end > frame->image_height)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rows [%u,%u) of %u", row_begin, row_end,
+                frame->image_height);
+  if (row_begin == row_end) return RT_OK;
+  if (!d_out) return fail(RT_ERR_INVALID_ARGUMENT, "d_out is NULL");
+  rt::TileDev t;
+  t.x = 0; t.y = row_begin; t.w = frame->image_width; t.h = row_end - row_begin;
+  t.first_pixel = 0;
+  t.out_stride = frame->image_width;
+  t.out_offset = 0;
+  std::vector<rt::TileDev> td(1, t);
+  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  return render_tiles_device(scene, frame, td, (uint64_t)t.w * t.h, resolve, d_out, s);
+}
+
+int rt_synchronize(void* stream) {
+  if (int rc = check_ready()) return rc;
+  RT_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : g.stream));
+  return RT_OK;
+}
+
+int rt_get_stats(rt_stats* out) {
+  if (int rc = check_ready()) return rc;
+  if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
+  RT_HIP(hipStreamSynchronize(g.last_stream ? g.last_stream : g.stream));
+  rt_stats s = g.last;
+  if (s.workgroups != 0) {
+    rt::Counters c;
+    RT_HIP(hipMemcpy(&c, g.counters, sizeof c, hipMemcpyDeviceToHost));
+    s.rays = c.rays;
+    s.samples = c.samples;
+    s.sphere_tests = c.rays * g.last.sphere_tests;
+    const int slot = (int)((g.launches - 1) % kEventRing);
+    float ms = 0.0f;
+    RT_HIP(hipEventElapsedTime(&ms, g.ev_begin[slot], g.ev_end[slot]));
+    s.kernel_ms = ms;
+  }
+  *out = s;
+  return RT_OK;
+}
+
+int rt_get_launch_ms(uint32_t n_last, float* out_ms) {
+  if (int rc = check_ready()) return rc;
+  if (n_last && !out_ms) return fail(RT_ERR_INVALID_ARGUMENT, "out_ms is NULL");
+  uint64_t n = n_last;
+  if (n > g.launches) n = g.launches;
+  if (n > (uint64_t)kEventRing) n = kEventRing;
+  for (uint64_t k = 0; k < n; ++k) {
+    const int slot = (int)((g.launches - n + k) % kEventRing);
+    RT_HIP(hipEventSynchronize(g.ev_end[slot]));
+    float ms = 0.0f;
+    RT_HIP(hipEventElapsedTime(&ms, g.ev_begin[slot], g.ev_end[slot]));
+    out_ms[k] = ms;
+  }
+  return (int)n;
+}
+
+int rt_render(const rt_request* req, float* out_rgb) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_request(req, false)) return rc;
+  if (!out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
+  rt_frame f = frame_of(req);
+  if (int rc = check_frame(&f)) return rc;
+  ScopedScene sc;
+  if (int rc = rt_scene_create(req->spheres, req->n_spheres, req->materials, req->n_materials, &sc.s))
+    return rc;
+  const size_t bytes = (size_t)f.image_width * f.image_height * 3 * sizeof(float);
+  ScopedDev d;
+  RT_HIP(hipMalloc(&d.p, bytes));
+  if (int rc = rt_render_rows_device_async(sc.s, &f, 0, f.image_height, 1, (float*)d.p, g.stream))
+    return rc;
+  RT_HIP(hipStreamSynchronize(g.stream));
+  RT_HIP(hipMemcpy(out_rgb, d.p, bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_render_tiles(const rt_request* req, float* out_sums) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_request(req, true)) return rc;
+  rt_frame f = frame_of(req);
+  if (int rc = check_frame(&f)) return rc;
+  if (req->n_tiles == 0) return RT_OK;
+  if (!out_sums) return fail(RT_ERR_INVALID_ARGUMENT, "out_sums is NULL");
+  std::vector<uint64_t> off(req->n_tiles);
+  std::vector<uint32_t> stride(req->n_tiles);
+  uint64_t total = 0;
+  for (uint32_t i = 0; i < req->n_tiles; ++i) {
+    off[i] = total;
+    stride[i] = req->tiles[i].width;
+    total += (uint64_t)req->tiles[i].width * req->tiles[i].height;
+  }
+  if (total == 0) return RT_OK;
+  ScopedScene sc;
+  if (int rc = rt_scene_create(req->spheres, req->n_spheres, req->materials, req->n_materials, &sc.s))
+    return rc;
+  const size_t bytes = (size_t)total * 3 * sizeof(float);
+  ScopedDev d;
+  RT_HIP(hipMalloc(&d.p, bytes));
+  if (int rc = rt_render_device_async(sc.s, &f, req->tiles, off.data(), stride.data(), req->n_tiles,
+                                      0, (float*)d.p, g.stream))
+    return rc;
+  RT_HIP(hipStreamSynchronize(g.stream));
+  RT_HIP(hipMemcpy(out_sums, d.p, bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_compose(const rt_tile* tiles, uint32_t n_tiles, const float* tile_sums, uint32_t image_width,
+               uint32_t image_height, uint32_t samples_per_pixel, float* out_rgb) {
+  if (!out_rgb || (n_tiles && (!tiles || !tile_sums)))
+    return fail(RT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (samples_per_pixel == 0) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel is 0");
+  if (int rc = check_tiles(tiles, n_tiles, image_width, image_height)) return rc;
+  // compose_final_framebuffer, src/cpu/mod.rs:51-83 (host arithmetic; a 25 MB scatter is not
+  // worth a round trip to the device when the sums are already on the host)
+  memset(out_rgb, 0, (size_t)image_width * image_height * 3 * sizeof(float));
+  const float scale = 1.0f / (float)samples_per_pixel;
+  size_t base = 0;
+  for (uint32_t j = 0; j < n_tiles; ++j) {
+    const rt_tile& t = tiles[j];
+    for (uint32_t yoff = 0; yoff < t.height; ++yoff) {
+      for (uint32_t xoff = 0; xoff < t.width; ++xoff) {
+        const float* c = tile_sums + 3 * (base + xoff + (size_t)yoff * t.width);
+        float* o = out_rgb + 3 * ((size_t)(t.x + xoff) + (size_t)(t.y + yoff) * image_width);
+        for (int k = 0; k < 3; ++k) {
+          float v = std::sqrt(c[k] * scale);
+          if (v < 0.0f) v = 0.0f; else if (v > 0.999f) v = 0.999f;   // NaN stays NaN
+          o[k] = v;
+        }
+      }
+    }
+    base += (size_t)t.width * t.height;
+  }
+  return RT_OK;
+}
+
+int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays, uint32_t seed,
+                  uint32_t flags, rt_ray_out* out) {
+  if (int rc = check_ready()) return rc;
+  if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  if (n_rays == 0) return RT_OK;
+  if (!rays || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL rays or out");
+  ScopedDev din, dout;
+  RT_HIP(hipMalloc(&din.p, (size_t)n_rays * sizeof(rt_ray_in)));
+  RT_HIP(hipMalloc(&dout.p, (size_t)n_rays * sizeof(rt_ray_out)));
+  RT_HIP(hipMemcpy(din.p, rays, (size_t)n_rays * sizeof(rt_ray_in), hipMemcpyHostToDevice));
+  rt::HookParams hp;
+  hp.scene = scene->dev;
+  hp.rays = (const rt_ray_in*)din.p;
+  hp.out = (rt_ray_out*)dout.p;
+  hp.n_rays = n_rays;
+  hp.seed = seed;
+  RT_HIP(rt::launch_hook(hp, (flags & RT_FLAG_STRICT_FP) != 0, g.stream));
+  RT_HIP(hipStreamSynchronize(g.stream));
+  RT_HIP(hipMemcpy(out, dout.p, (size_t)n_rays * sizeof(rt_ray_out), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// Internal declarations shared by the kernel file and the host side of librt_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_abi.h"
+
+namespace rt {
+
+constexpr int kWave = 64;
+constexpr int kThreads = 512;           // 8 waves per workgroup
+constexpr int kWavesPerWg = kThreads / kWave;
+constexpr int kRaysPerLane = 2;         // independent paths blocked into one lane
+constexpr int kQueueSlots = 16;         // deferred-candidate slots per path (u16 each)
+constexpr int kScanUnroll = 4;          // spheres per unrolled block of the scan
+constexpr uint32_t kChunkSpheres = 2048; // sphere records resident in LDS at a time (32 KiB)
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic
+constexpr uint32_t kTargetItems = 1u << 20; // below this many pixels, split samples over lanes
+
+// One tile of the request as the kernel sees it.
+struct TileDev {
+  uint32_t x, y, w, h;
+  uint32_t first_pixel;   // exclusive prefix sum of w*h over the tile list
+  uint32_t out_stride;    // pixels between rows of this tile in the output
+  uint64_t out_offset;    // pixel index of the tile's first pixel in the output
+};
+
+// Device copy of a World (reference src/main.rs:168-172), split hot/cold:
+//   geom[i] = (cx, cy, cz, radius*radius)       read by every ray for every sphere
+//   aux[i]  = (radius, material_id bits)        read once per hit
+//   mat[2m] = (r, g, b, flags bits), mat[2m+1] = (metallic_strength, ir, 0, 0)
+struct SceneDev {
+  const float4* geom;
+  const float2* aux;
+  const float4* mat;
+  uint32_t n_spheres;
+  uint32_t n_materials;
+};
+
+struct Counters {
+  uint32_t next_grab;   // work-distribution cursor, in units of kItemsPerGrab items
+  uint32_t pad;
+  unsigned long long rays;     // World::hit calls
+  unsigned long long samples;  // shoot_ray calls from the pixel loop
+};
+
+struct TraceParams {
+  SceneDev scene;
+  rt_camera cam;
+  float origin[3];        // view_inv * (0,0,0,1), a per-frame constant (src/main.rs:71-72)
+  uint32_t width, height;
+  uint32_t max_depth, spp;
+  uint32_t seed_a, seed_b;  // rt_rng_seed_a/b(seed)
+  uint32_t slices;          // lanes sharing one pixel's samples
+  uint32_t n_tiles;
+  uint32_t total_pixels;
+  uint32_t total_items;     // total_pixels * slices
+  uint64_t out_pixels;      // pixels in one slice of the output (slice stride)
+  TileDev tile0;            // the tile list when n_tiles == 1
+  const TileDev* tiles;     // otherwise
+  float* out;               // final buffer (slices == 1) or partial-sum buffer
+  int resolve;              // apply x*(1/spp), sqrt, clamp on the way out (slices == 1 only)
+  float inv_spp;
+  Counters* counters;
+};
+
+struct ReduceParams {
+  const float* partial;   // [slices][out_pixels][3]
+  float* out;             // [out_pixels][3]
+  uint64_t out_pixels;
+  uint32_t slices;
+  int resolve;
+  float inv_spp;
+};
+
+struct HookParams {
+  SceneDev scene;
+  const rt_ray_in* rays;
+  rt_ray_out* out;
+  uint32_t n_rays;
+  uint32_t seed;
+};
+
+// Launchers implemented in rt_kernels.hip.  `strict` selects the non-contracted discriminant.
+size_t trace_lds_bytes(uint32_t n_spheres);
+hipError_t trace_max_blocks_per_cu(bool strict, bool multi, size_t lds_bytes, int* out);
+hipError_t launch_trace(const TraceParams& p, bool strict, int blocks, hipStream_t stream);
+hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream);
+hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream);
+
+}  // namespace rt

@@ -1,0 +1,669 @@
+// rt_kernels.hip - hand-written gfx950 (CDNA4) kernels of the path tracer.
+//
+// What runs here is the reference's per-tile pixel/sample loop, execute_job
+// (src/cpu/job.rs:36-74), with everything it calls: Camera::get_ray (src/main.rs:70-83),
+// World::shoot_ray (src/main.rs:191-263), World::hit / Sphere::hit (src/main.rs:128-189),
+// reflect / refract / reflectance (src/main.rs:162-166, 312-323) and the random helpers
+// (src/main.rs:266-286).
+//
+// Shape of the main kernel (trace_kernel):
+//  * Persistent waves.  A lane owns kRaysPerLane independent paths.  A work item is
+//    (pixel, slice of that pixel's samples); a lane runs its item's samples one after the other
+//    and keeps the running sum in registers, so the per-pixel sum is formed in sample order like
+//    `pixel_color += color` (src/cpu/job.rs:58).  When a path ends the lane starts the next
+//    sample, and when the item ends it takes the next item of its wave's reservation (one
+//    global atomic per 64 items).  Lanes therefore never wait for the longest path of their
+//    wave: at max_depth 50 this is what keeps the vector ALU busy.
+//  * The recursion of shoot_ray is a loop with a running throughput; random numbers are drawn
+//    in the reference's order from the counter stream of rt_rng.h.
+//  * World::hit is split in two.  The scan evaluates, for every sphere, only the discriminant
+//    half_b^2 - a*c (11 VALU instructions with fused multiply-adds for the 17 flops of
+//    src/main.rs:131-135); the sphere record (cx,cy,cz,r^2) is one wave-uniform 16-byte LDS
+//    read shared by both paths of every lane.  A sphere whose discriminant is not negative is
+//    appended to a small per-path queue in LDS.  After the scan each lane replays its own
+//    queue through the reference's exact Sphere::hit arithmetic (IEEE sqrt and divide, no
+//    contraction) in storage order, so the closest-hit decision and t are the reference's.
+//    Replaying per lane keeps all 64 lanes busy in the slow part instead of one lane per
+//    triggering sphere.
+//  * Scenes larger than kChunkSpheres are streamed through the same LDS buffer chunk by chunk
+//    by the whole workgroup (MULTI = true), carrying closest-hit across chunks.
+//  * STRICT = true evaluates the discriminant in the reference's operation order without
+//    fused multiply-adds (17 instructions); every hit decision is then bit-identical to the
+//    CPU restatement.  STRICT = false differs only for rays within rounding of tangency.
+//
+// Build flags that matter: -ffp-contract=off (every fma below is written out by hand),
+// -fno-slp-vectorize (auto-packing into v_pk_*_f32 costs more shuffles than it saves here).
+#include "rt_internal.h"
+
+#include <float.h>
+
+#include "../../include/rt_rng.h"
+
+namespace rt {
+namespace {
+
+constexpr int R = kRaysPerLane;
+constexpr int Q = kQueueSlots;
+constexpr int U = kScanUnroll;
+constexpr float kTMin = 0.001f;  // src/main.rs:196
+constexpr float kTMax = FLT_MAX; // f32::MAX, src/main.rs:196
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 scale(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 divs(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// glam: (x*x') + (y*y') + (z*z'), left to right, no contraction
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+// glam: v * (1.0 / sqrt(dot(v, v)))
+__device__ __forceinline__ V3 normalize(V3 a) {
+  float len = __builtin_sqrtf(dot(a, a));
+  float rcp = 1.0f / len;
+  return scale(a, rcp);
+}
+
+// The random stream of one path.  `draws` is only read by the per-ray test hook.
+struct PathRng {
+  rt_rng g;
+  uint32_t draws;
+};
+__device__ __forceinline__ float next_f32(PathRng& r) {
+  r.draws++;
+  return rt_rng_next_f32(&r.g);
+}
+
+// random_vec3, src/main.rs:266-271
+__device__ __forceinline__ V3 random_vec3(PathRng& r) {
+  float x = next_f32(r) * 2.0f - 1.0f;
+  float y = next_f32(r) * 2.0f - 1.0f;
+  float z = next_f32(r) * 2.0f - 1.0f;
+  return mk(x, y, z);
+}
+// random_in_unit_sphere_vec3, src/main.rs:273-282
+__device__ __forceinline__ V3 random_in_unit_sphere(PathRng& r) {
+  for (;;) {
+    V3 v = random_vec3(r);
+    if (dot(v, v) >= 1.0f) continue;
+    return v;
+  }
+}
+// reflect, src/main.rs:312-315
+__device__ __forceinline__ V3 reflect(V3 input, V3 normal) {
+  float dn = 2.0f * dot(input, normal);
+  return sub(input, scale(normal, dn));
+}
+// refract, src/main.rs:317-323
+__device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat) {
+  float cos_theta = __builtin_fminf(dot(neg(uv), n), 1.0f);
+  V3 out_perp = scale(add(uv, scale(n, cos_theta)), etai_over_etat);
+  float k = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot(out_perp, out_perp)));
+  return add(out_perp, scale(n, k));
+}
+// reflectance, src/main.rs:162-166; powf(x, 5.0) as three multiplies (within 2 ulp of libm)
+__device__ __forceinline__ float reflectance(float cosine, float ref_index) {
+  float r0 = (1.0f - ref_index) / (1.0f + ref_index);
+  r0 = r0 * r0;
+  float x = 1.0f - cosine;
+  float x2 = x * x;
+  float x4 = x2 * x2;
+  return r0 + (1.0f - r0) * (x4 * x);
+}
+// sky, src/main.rs:256-262
+__device__ __forceinline__ V3 sky(V3 dir) {
+  V3 u = normalize(dir);
+  float t = 0.5f * (u.y + 1.0f);
+  float s = 1.0f - t;
+  return mk(s * 1.0f + t * 0.5f, s * 1.0f + t * 0.7f, s * 1.0f + t * 1.0f);
+}
+// f32::clamp of Rust (NaN stays NaN), as used by compose_final_framebuffer, src/cpu/mod.rs:73-75
+__device__ __forceinline__ float rust_clamp(float v, float lo, float hi) {
+  if (v < lo) return lo;
+  if (v > hi) return hi;
+  return v;
+}
+__device__ __forceinline__ float resolve_channel(float sum, float inv_spp) {
+  return rust_clamp(__builtin_sqrtf(sum * inv_spp), 0.0f, 0.999f); // src/cpu/mod.rs:67-75
+}
+
+// ---- exact Sphere::hit on one candidate, src/main.rs:128-150 -------------------------------
+// Updates (closest, best) exactly like the body of World::hit's loop, src/main.rs:182-185.
+__device__ __forceinline__ void exact_hit(float4 s, uint32_t index, V3 o, V3 d, float a,
+                                          float& closest, uint32_t& best) {
+  V3 oc = sub(o, mk(s.x, s.y, s.z));
+  float half_b = dot(oc, d);
+  float c = dot(oc, oc) - s.w;   // s.w = radius * radius
+  float discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0f) return;
+  float sqrtd = __builtin_sqrtf(discriminant);
+  float root = (-half_b - sqrtd) / a;
+  if (root < kTMin || closest < root) {
+    root = (-half_b + sqrtd) / a;
+    if (root < kTMin || closest < root) return;
+  }
+  closest = root;
+  best = index;
+}
+
+// ---- one segment's scatter decision, the body of shoot_ray, src/main.rs:196-251 -------------
+struct Bounce {
+  uint32_t kind;
+  uint32_t material;
+  bool front;
+  bool scattered;
+  V3 point, normal;
+  V3 dir;    // scattered direction
+  V3 atten;  // factor on the next segment's radiance
+};
+
+__device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, float t,
+                                            uint32_t sphere, PathRng& rng) {
+  Bounce b;
+  const float4 g = sc.geom[sphere];
+  const float2 aux = sc.aux[sphere];
+  const float radius = aux.x;
+  b.material = __float_as_uint(aux.y);
+  const float4 m0 = sc.mat[2 * b.material];
+  const float4 m1 = sc.mat[2 * b.material + 1];
+  const uint32_t flags = __float_as_uint(m0.w);
+  const V3 color = mk(m0.x, m0.y, m0.z);
+
+  b.point = add(o, scale(d, t));                                  // Ray::at
+  V3 outward = divs(sub(b.point, mk(g.x, g.y, g.z)), radius);      // src/main.rs:154
+  b.front = dot(d, outward) < 0.0f;                               // set_face_normal
+  b.normal = b.front ? outward : neg(outward);
+  b.scattered = true;
+
+  if (flags & RT_MAT_DIELECTRIC) {                                // src/main.rs:201-227
+    b.kind = RT_KIND_DIELECTRIC;
+    float ir = m1.y;
+    float ratio = b.front ? 1.0f / ir : ir;
+    V3 u = normalize(d);
+    float cos_theta = __builtin_fminf(dot(neg(u), b.normal), 1.0f);
+    float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+    bool cannot_refract = (ratio * sin_theta) > 1.0f;
+    bool do_reflect = cannot_refract;
+    if (!cannot_refract) do_reflect = reflectance(cos_theta, ratio) > next_f32(rng);  // `||`
+    b.dir = do_reflect ? reflect(u, b.normal) : refract(u, b.normal, ratio);
+    b.atten = mk(1.0f, 1.0f, 1.0f);
+  } else if (flags & RT_MAT_METALLIC) {                           // src/main.rs:228-242
+    b.kind = RT_KIND_METAL;
+    V3 reflected = reflect(d, b.normal);
+    float fuzz = 1.0f - m1.x;
+    b.dir = add(reflected, scale(random_in_unit_sphere(rng), fuzz));
+    if (dot(reflected, b.normal) > 0.0f) {
+      b.atten = mul(color, color);   // albedo applied twice, src/main.rs:199,236-237,242
+    } else {
+      b.atten = mk(0.0f, 0.0f, 0.0f);
+      b.scattered = false;
+    }
+  } else {                                                        // src/main.rs:243-251
+    b.kind = RT_KIND_DIFFUSE;
+    b.dir = add(b.normal, normalize(random_in_unit_sphere(rng)));
+    b.atten = color;
+  }
+  return b;
+}
+
+// ---- per-path state -------------------------------------------------------------------------
+struct Path {
+  // current segment
+  float ox, oy, oz;
+  float dx, dy, dz;
+  float a;          // dir.length_squared(), src/main.rs:132
+  float closest;
+  uint32_t best;
+  uint32_t cnt;     // queued candidates
+  bool alive;
+  // path
+  float tr, tg, tb; // throughput
+  uint32_t depth;   // segments the path may still trace
+  PathRng rng;
+  // item
+  bool has_item;
+  float ar, ag, ab; // running sum of the item's samples
+  float fx, fy;     // pixel coordinates as f32
+  uint32_t pixel;   // y * W + x
+  uint32_t out_index;
+  uint32_t sample, sample_end;
+};
+
+// Append to / replay the deferred-candidate queue.  Layout: q[(r*Q + slot)*64 + lane], u16,
+// holding indices local to the sphere chunk resident in LDS.
+template <bool STRICT>
+__device__ __forceinline__ void test_sphere(const float4 s, uint32_t local_index, Path (&P)[R],
+                                            uint16_t* q, uint32_t lane, bool& flush) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float ocx = P[r].ox - s.x, ocy = P[r].oy - s.y, ocz = P[r].oz - s.z;
+    float disc;
+    if (STRICT) {
+      const float half_b = (ocx * P[r].dx + ocy * P[r].dy) + ocz * P[r].dz;
+      const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - s.w;
+      disc = half_b * half_b - P[r].a * c;
+    } else {
+      const float half_b =
+          __builtin_fmaf(ocz, P[r].dz, __builtin_fmaf(ocy, P[r].dy, ocx * P[r].dx));
+      const float c = __builtin_fmaf(
+          ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
+      disc = __builtin_fmaf(half_b, half_b, -(P[r].a * c));
+    }
+    const bool trig = !(disc < 0.0f);   // the reference returns early on `discriminant < 0.0`
+    if (__builtin_amdgcn_ballot_w64(trig) != 0) {   // wave-uniform: skipped for most spheres
+      if (trig && P[r].alive) {
+        q[(r * Q + P[r].cnt) * kWave + lane] = (uint16_t)local_index;
+        P[r].cnt++;
+      }
+      // A block of U spheres can add at most U entries per path: ask for a replay while
+      // every queue still has room for the rest of this block and the next one.
+      if (__builtin_amdgcn_ballot_w64(P[r].cnt >= (uint32_t)(Q - U)) != 0) flush = true;
+    }
+  }
+}
+
+__device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, uint32_t chunk_base,
+                                             const uint16_t* q, uint32_t lane) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const uint32_t n = P[r].cnt;
+    const V3 o = mk(P[r].ox, P[r].oy, P[r].oz), d = mk(P[r].dx, P[r].dy, P[r].dz);
+    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0; ++k) {
+      if (k < n) {
+        const uint32_t li = q[(r * Q + k) * kWave + lane];
+        exact_hit(sph[li], chunk_base + li, o, d, P[r].a, P[r].closest, P[r].best);
+      }
+    }
+    P[r].cnt = 0;
+  }
+}
+
+// Scan one LDS-resident chunk of `cn` spheres for all paths of the wave.
+template <bool STRICT>
+__device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, uint32_t cn,
+                                           uint32_t chunk_base, uint16_t* q, uint32_t lane) {
+  uint32_t i = 0;
+  while (i < cn) {
+    bool flush = false;
+    for (; i + U <= cn && !flush; i += U) {
+      float4 s[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) s[u] = sph[i + u];
+#pragma unroll
+      for (int u = 0; u < U; ++u) test_sphere<STRICT>(s[u], i + u, P, q, lane, flush);
+    }
+    if (!flush) {
+      for (; i < cn; ++i) test_sphere<STRICT>(sph[i], i, P, q, lane, flush);
+    }
+    replay_queue(P, sph, chunk_base, q, lane);
+  }
+}
+
+// Reserve work for the lanes of this wave whose `need` is set.  Returns the lane's item or
+// kNone once the frame's items are exhausted.  Must be called by all 64 lanes.
+__device__ __forceinline__ uint32_t wave_fetch(bool need, uint32_t& next, uint32_t& end,
+                                               bool& exhausted, const TraceParams& p,
+                                               uint32_t lane) {
+  uint32_t item = kNone;
+  unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
+  while (mask != 0 && !exhausted) {
+    if (next == end) {
+      uint32_t g = 0;
+      if (lane == 0) g = atomicAdd(&p.counters->next_grab, 1u);
+      g = __builtin_amdgcn_readfirstlane(g);
+      const unsigned long long first = (unsigned long long)g * kItemsPerGrab;
+      if (first >= p.total_items) {
+        exhausted = true;
+        break;
+      }
+      next = (uint32_t)first;
+      end = p.total_items - next < kItemsPerGrab ? p.total_items : next + kItemsPerGrab;
+    }
+    const uint32_t avail = end - next;
+    const bool asking = (mask >> lane) & 1ull;
+    const uint32_t rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    const bool mine = asking && rank < avail;
+    if (mine) item = next + rank;
+    const uint32_t want = __builtin_popcountll(mask);
+    next += want < avail ? want : avail;
+    mask = __builtin_amdgcn_ballot_w64(asking && !mine);
+  }
+  return item;
+}
+
+__device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TraceParams& p) {
+  uint32_t g = item, sl = 0;
+  if (p.slices != 1) {
+    g = item / p.slices;
+    sl = item - g * p.slices;
+  }
+  TileDev t = p.tile0;
+  if (p.n_tiles != 1) {
+    uint32_t lo = 0, hi = p.n_tiles;   // largest k with tiles[k].first_pixel <= g
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (p.tiles[mid].first_pixel <= g) lo = mid; else hi = mid;
+    }
+    t = p.tiles[lo];
+  }
+  const uint32_t local = g - t.first_pixel;
+  const uint32_t ty = local / t.w;
+  const uint32_t tx = local - ty * t.w;
+  const uint32_t px = t.x + tx, py = t.y + ty;
+  P.fx = (float)px;
+  P.fy = (float)py;
+  P.pixel = py * p.width + px;
+  P.out_index = (uint32_t)(t.out_offset + (uint64_t)ty * t.out_stride + tx + sl * p.out_pixels);
+  P.sample = (uint32_t)(((unsigned long long)sl * p.spp) / p.slices);
+  P.sample_end = (uint32_t)(((unsigned long long)(sl + 1) * p.spp) / p.slices);
+  P.ar = P.ag = P.ab = 0.0f;
+  P.has_item = true;
+}
+
+// The sample loop body up to the first segment: jitter (src/cpu/job.rs:50-54) and
+// Camera::get_ray (src/main.rs:70-83, Mat4*Vec4 = ((c0*x + c1*y) + c2*z) + c3*w).
+__device__ __forceinline__ void start_sample(Path& P, const TraceParams& p) {
+  P.rng.g = rt_rng_from_pixel(rt_rng_pixel_a(p.seed_a, P.pixel), rt_rng_pixel_b(p.seed_b, P.pixel),
+                              P.sample);
+  P.rng.draws = 0;
+  float u = (P.fx + next_f32(P.rng)) / (float)p.width;
+  float v = (P.fy + next_f32(P.rng)) / (float)p.height;
+  u = u * 2.0f - 1.0f;
+  v = v * 2.0f - 1.0f;
+  const float* PI = p.cam.proj_inv;
+  const float* VI = p.cam.view_inv;
+  float d4[3], w[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    d4[i] = ((PI[i] * u + PI[4 + i] * v) + PI[8 + i] * 0.0f) + PI[12 + i] * 1.0f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    w[i] = ((VI[i] * d4[0] + VI[4 + i] * d4[1]) + VI[8 + i] * d4[2]) + VI[12 + i] * 0.0f;
+  const V3 dir = normalize(mk(w[0], w[1], w[2]));
+  P.ox = p.origin[0]; P.oy = p.origin[1]; P.oz = p.origin[2];
+  P.dx = dir.x; P.dy = dir.y; P.dz = dir.z;
+  P.a = dot(dir, dir);
+  P.tr = P.tg = P.tb = 1.0f;
+  P.depth = p.max_depth;
+  P.alive = true;
+}
+
+__device__ __forceinline__ void write_item(const Path& P, const TraceParams& p) {
+  float r = P.ar, g = P.ag, b = P.ab;
+  if (p.resolve) {
+    r = resolve_channel(r, p.inv_spp);
+    g = resolve_channel(g, p.inv_spp);
+    b = resolve_channel(b, p.inv_spp);
+  }
+  float* o = p.out + 3ull * P.out_index;
+  o[0] = r; o[1] = g; o[2] = b;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
+  unsigned long long s = v;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+  return s;
+}
+
+template <bool STRICT, bool MULTI>
+__global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
+  extern __shared__ float4 lds[];
+  const uint32_t n = p.scene.n_spheres;
+  const uint32_t cap = MULTI ? kChunkSpheres : n;
+  float4* sph = lds;
+  uint16_t* qall = reinterpret_cast<uint16_t*>(lds + cap);
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = threadIdx.x / kWave;
+  uint16_t* q = qall + wave * (R * Q * kWave);
+
+  if (!MULTI) {
+    for (uint32_t i = threadIdx.x; i < n; i += kThreads) sph[i] = p.scene.geom[i];
+    __syncthreads();
+  }
+
+  Path P[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    P[r].alive = false;
+    P[r].has_item = false;
+    P[r].sample = P[r].sample_end = 0;
+    P[r].cnt = 0;
+    P[r].ox = P[r].oy = P[r].oz = 0.0f;
+    P[r].dx = P[r].dy = P[r].dz = 0.0f;
+    P[r].a = 1.0f;
+    P[r].closest = kTMax;
+    P[r].best = kNone;
+  }
+  uint32_t grab_next = 0, grab_end = 0;
+  bool exhausted = false;
+  uint32_t n_rays = 0, n_samples = 0;
+
+  for (;;) {
+    // ---- refill: next sample of the item, or the next item ------------------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool need = !P[r].alive && P[r].sample >= P[r].sample_end;
+      if (need && P[r].has_item) {
+        write_item(P[r], p);
+        P[r].has_item = false;
+      }
+      const uint32_t item = wave_fetch(need, grab_next, grab_end, exhausted, p, lane);
+      if (need && item != kNone) setup_item(P[r], item, p);
+      if (!P[r].alive && P[r].has_item && P[r].sample < P[r].sample_end) {
+        start_sample(P[r], p);
+        n_samples++;
+      }
+    }
+    bool any_alive = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) any_alive = any_alive || P[r].alive;
+    const bool wave_alive = __builtin_amdgcn_ballot_w64(any_alive) != 0;
+    if (MULTI) {
+      if (!__syncthreads_or(wave_alive ? 1 : 0)) break;   // workgroup-uniform
+    } else {
+      if (!wave_alive) break;
+    }
+
+    // ---- World::hit --------------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      P[r].closest = kTMax;
+      P[r].best = kNone;
+      P[r].cnt = 0;
+    }
+    if (MULTI) {
+      for (uint32_t base = 0; base < n; base += kChunkSpheres) {
+        const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
+        __syncthreads();   // every wave is done with the previous chunk
+        for (uint32_t i = threadIdx.x; i < cn; i += kThreads) sph[i] = p.scene.geom[base + i];
+        __syncthreads();
+        scan_chunk<STRICT>(P, sph, cn, base, q, lane);
+      }
+    } else {
+      scan_chunk<STRICT>(P, sph, n, 0, q, lane);
+    }
+
+    // ---- the rest of shoot_ray's body ----------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (P[r].alive) {
+        n_rays++;
+        const V3 o = mk(P[r].ox, P[r].oy, P[r].oz), d = mk(P[r].dx, P[r].dy, P[r].dz);
+        bool ended;
+        V3 radiance = mk(0.0f, 0.0f, 0.0f);
+        if (P[r].best == kNone) {
+          radiance = mul(mk(P[r].tr, P[r].tg, P[r].tb), sky(d));
+          ended = true;
+        } else {
+          const Bounce b = shade_hit(p.scene, o, d, P[r].closest, P[r].best, P[r].rng);
+          if (!b.scattered) {
+            ended = true;
+          } else {
+            if (b.kind != RT_KIND_DIELECTRIC) {
+              P[r].tr *= b.atten.x; P[r].tg *= b.atten.y; P[r].tb *= b.atten.z;
+            }
+            P[r].ox = b.point.x; P[r].oy = b.point.y; P[r].oz = b.point.z;
+            P[r].dx = b.dir.x; P[r].dy = b.dir.y; P[r].dz = b.dir.z;
+            P[r].a = dot(b.dir, b.dir);
+            P[r].depth--;
+            ended = P[r].depth == 0;   // `if depth <= 0 { return black }`, src/main.rs:192-194
+          }
+        }
+        if (ended) {
+          P[r].ar += radiance.x; P[r].ag += radiance.y; P[r].ab += radiance.z;
+          P[r].alive = false;
+          P[r].sample++;
+        }
+      }
+    }
+  }
+
+  const unsigned long long rays = wave_sum(n_rays);
+  const unsigned long long samples = wave_sum(n_samples);
+  if (lane == 0) {
+    atomicAdd(&p.counters->rays, rays);
+    atomicAdd(&p.counters->samples, samples);
+  }
+}
+
+// Sum the slices of each pixel in slice order and optionally resolve.
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
+  const uint64_t n = p.out_pixels * 3ull;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    float s = p.partial[i];
+    for (uint32_t k = 1; k < p.slices; ++k) s += p.partial[(uint64_t)k * n + i];
+    p.out[i] = p.resolve ? resolve_channel(s, p.inv_spp) : s;
+  }
+}
+
+// Per-ray test hook: one World::hit and one scatter decision per input ray, through the same
+// scan / replay / shade code as the main kernel.  Path slot 0 of each lane carries the ray.
+template <bool STRICT>
+__global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
+  extern __shared__ float4 lds[];
+  float4* sph = lds;
+  uint16_t* qall = reinterpret_cast<uint16_t*>(lds + kChunkSpheres);
+  const uint32_t lane = threadIdx.x & (kWave - 1);
+  const uint32_t wave = threadIdx.x / kWave;
+  uint16_t* q = qall + wave * (R * Q * kWave);
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  const bool live = i < p.n_rays;
+
+  Path P[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    P[r].alive = false;
+    P[r].cnt = 0;
+    P[r].ox = P[r].oy = P[r].oz = 0.0f;
+    P[r].dx = P[r].dy = P[r].dz = 0.0f;
+    P[r].a = 1.0f;
+    P[r].closest = kTMax;
+    P[r].best = kNone;
+  }
+  if (live) {
+    const rt_ray_in in = p.rays[i];
+    P[0].ox = in.ox; P[0].oy = in.oy; P[0].oz = in.oz;
+    P[0].dx = in.dx; P[0].dy = in.dy; P[0].dz = in.dz;
+    P[0].a = dot(mk(in.dx, in.dy, in.dz), mk(in.dx, in.dy, in.dz));
+    P[0].alive = true;
+  }
+  const uint32_t n = p.scene.n_spheres;
+  for (uint32_t base = 0; base < n; base += kChunkSpheres) {
+    const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < cn; k += kThreads) sph[k] = p.scene.geom[base + k];
+    __syncthreads();
+    scan_chunk<STRICT>(P, sph, cn, base, q, lane);
+  }
+  if (!live) return;
+
+  rt_ray_out out;
+  const V3 o = mk(P[0].ox, P[0].oy, P[0].oz), d = mk(P[0].dx, P[0].dy, P[0].dz);
+  PathRng rng;
+  rng.g = rt_rng_init(p.seed, i, 0);
+  rng.draws = 0;
+  out.sphere = 0; out.material = 0; out.front_face = 0; out.scattered = 0; out.draws = 0;
+  out.t = 0.0f;
+  out.px = out.py = out.pz = 0.0f;
+  out.nx = out.ny = out.nz = 0.0f;
+  out.sx = out.sy = out.sz = 0.0f;
+  if (P[0].best == kNone) {
+    const V3 s = sky(d);
+    out.hit = 0;
+    out.kind = RT_KIND_MISS;
+    out.ar = s.x; out.ag = s.y; out.ab = s.z;
+  } else {
+    const Bounce b = shade_hit(p.scene, o, d, P[0].closest, P[0].best, rng);
+    out.hit = 1;
+    out.sphere = P[0].best;
+    out.material = b.material;
+    out.kind = b.kind;
+    out.front_face = b.front ? 1u : 0u;
+    out.scattered = b.scattered ? 1u : 0u;
+    out.draws = rng.draws;
+    out.t = P[0].closest;
+    out.px = b.point.x; out.py = b.point.y; out.pz = b.point.z;
+    out.nx = b.normal.x; out.ny = b.normal.y; out.nz = b.normal.z;
+    out.sx = b.dir.x; out.sy = b.dir.y; out.sz = b.dir.z;
+    out.ar = b.atten.x; out.ag = b.atten.y; out.ab = b.atten.z;
+  }
+  p.out[i] = out;
+}
+
+constexpr size_t kQueueBytes = (size_t)kWavesPerWg * R * Q * kWave * sizeof(uint16_t);
+
+}  // namespace
+
+size_t trace_lds_bytes(uint32_t n_spheres) {
+  const size_t cap = n_spheres > kChunkSpheres ? kChunkSpheres : n_spheres;
+  return cap * sizeof(float4) + kQueueBytes;
+}
+
+template <bool STRICT, bool MULTI>
+static hipError_t occupancy(size_t lds, int* out) {
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, trace_kernel<STRICT, MULTI>, kThreads, lds);
+}
+
+hipError_t trace_max_blocks_per_cu(bool strict, bool multi, size_t lds, int* out) {
+  if (strict) return multi ? occupancy<true, true>(lds, out) : occupancy<true, false>(lds, out);
+  return multi ? occupancy<false, true>(lds, out) : occupancy<false, false>(lds, out);
+}
+
+hipError_t launch_trace(const TraceParams& p, bool strict, int blocks, hipStream_t stream) {
+  const bool multi = p.scene.n_spheres > kChunkSpheres;
+  const size_t lds = trace_lds_bytes(p.scene.n_spheres);
+  const dim3 grid(blocks), block(kThreads);
+  if (strict) {
+    if (multi) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, stream, p);
+  } else {
+    if (multi) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, stream, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream) {
+  const uint64_t n = p.out_pixels * 3ull;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream) {
+  if (p.n_rays == 0) return hipSuccess;
+  const size_t lds = kChunkSpheres * sizeof(float4) + kQueueBytes;
+  const dim3 grid((p.n_rays + kThreads - 1) / kThreads), block(kThreads);
+  if (strict) hipLaunchKernelGGL((hook_kernel<true>), grid, block, lds, stream, p);
+  else hipLaunchKernelGGL((hook_kernel<false>), grid, block, lds, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace rt

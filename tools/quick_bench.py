@@ -1,0 +1,52 @@
+"""Developer benchmark: time the path-tracing kernel on one configuration and print the
+roofline fraction.  Usage: python tools/quick_bench.py [grid_hi] [width] [height] [spp] [flags]
+The scene comes from the product's host mirror when available, else from the test oracle
+(this is a developer tool, not the product path)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+import oracle_lib as O  # noqa: E402
+from ray_tracing_amd import hip  # noqa: E402
+
+PEAK_TFLOPS = 157.3
+
+
+def main():
+    hi = int(sys.argv[1]) if len(sys.argv) > 1 else 11
+    w = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
+    h = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
+    spp = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+    flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    reps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+    hip.init(0)
+    s, m = O.random_world(1, -hi, hi)
+    cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, w / h)
+    scene = hip.Scene(s, m)
+    frame = hip.make_frame(cam, w, h, spp, 50, 1, flags)
+    out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rep in range(reps):
+        hip.render_rows_device_async(scene, frame, 0, h, True, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        st = hip.get_stats()
+        ms = st.kernel_ms
+        tflops = 17.0 * st.sphere_tests / (ms * 1e-3) * 1e-12
+        print("N=%d %dx%d spp=%d flags=%d: kernel %.2f ms  %.1f Msamples/s  rays/sample %.3f  "
+              "%.2f Gtests/s  %.2f TFLOP/s = %.1f%% of %.1f  (wg %d x %d thr, slices %d)"
+              % (len(s), w, h, spp, flags, ms, st.samples / ms * 1e-3, st.rays / max(st.samples, 1),
+                 st.sphere_tests / ms * 1e-6, tflops, 100 * tflops / PEAK_TFLOPS, PEAK_TFLOPS,
+                 st.workgroups, st.threads_per_workgroup, st.slices), flush=True)
+    img = out.cpu().numpy()
+    print("mean rgb", np.nanmean(img, axis=(0, 1)), "nan px", int(np.isnan(img).any(axis=2).sum()))
+
+
+if __name__ == "__main__":
+    main()
