@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s on the 1080p RTIOW-final scene (488 spheres, 100 spp,
+max_depth 50) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one full frame: every pixel's `spp` paths through the HIP kernel behind the C ABI
+(rt_render_device_async), scene resident in HBM.  With N > 1 the frame's rows are dealt to the
+ranks in blocks of 8, each rank renders its blocks and one RCCL gather brings the framebuffer
+to rank 0 (strong scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
+
+  value      whole-job Msamples/s = W*H*spp*steps / max-over-ranks wall time
+  roofline   dominant kernel (trace_kernel) against the FP32 vector-ALU peak: achieved =
+             17 flop * n_spheres * rays / kernel time, with rays counted by the kernel itself
+             and kernel time from HIP events on the launch stream (rank 0's launches)
+  cpu_baseline  the CPU restatement of the reference's multithreaded tile renderer
+             (oracle/, kind "port") timed on this host's cores on a reduced sample of the
+             same workload (N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz (MI355X)
+FLOP_PER_TEST = 17              # one ray/sphere discriminant, src/main.rs:131-135 with a hoisted
+
+CONFIGS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "rtiow488_1080p_100spp_d50": dict(grid=(-11, 11), width=1920, height=1080, spp=100, depth=50),
+    # configs[2]: same scene at 4K, 500 spp
+    "rtiow488_2160p_500spp_d50": dict(grid=(-11, 11), width=3840, height=2160, spp=500, depth=50),
+    # configs[3]: 10 004 spheres, LDS-chunked scan
+    "rtiow10k_1080p_64spp_d50": dict(grid=(-50, 50), width=1920, height=1080, spp=64, depth=50),
+    # configs[4]: dielectric-heavy
+    "glass488_1080p_1024spp_d50": dict(grid=(-11, 11), width=1920, height=1080, spp=1024, depth=50,
+                                       diffuse_below=0.1, metal_below=0.2, glass=True),
+}
+DEFAULT_CONFIG = "rtiow488_1080p_100spp_d50"
+
+
+def cpu_baseline(cfg, seed):
+    """Time the oracle's dispatch_work_cpu_multithreaded on a bounded sample of the workload:
+    the same scene, camera, depth and per-pixel path distribution at 1/2 the resolution and
+    a bounded number of samples per pixel (cost is linear in pixels x spp)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = min(16, os.cpu_count() or 1)
+    w, h, spp = cfg["width"] // 2, cfg["height"] // 2, 100
+    lo, hi = cfg["grid"]
+    if (hi - lo) ** 2 > 2000:
+        spp = 4
+    s, m = O.random_world(1, lo, hi, cfg.get("diffuse_below", 0.8), cfg.get("metal_below", 0.95),
+                          1 if cfg.get("glass") else 0)
+    cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, w / h)
+    _, secs, ctr = O.render(s, m, cam, w, h, spp, cfg["depth"], seed, mode=O.RO_MODE_RECURSIVE,
+                            threads=cores)
+    return {
+        "value": round(ctr.samples / secs * 1e-6, 4),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%dx%d @ %d spp, same scene/camera/max_depth (%d samples, %.1f s, %.3f rays/sample)"
+                  % (w, h, spp, ctr.samples, secs, ctr.rays / max(ctr.samples, 1)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    import torch
+    import torch.distributed as dist
+
+    from ray_tracing_amd import hip, host, multi_gpu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
+                         "--nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    hip.init(local_rank)
+
+    # host side: the reference's scene, camera and request, from the product's host mirror
+    W, H, spp, depth = cfg["width"], cfg["height"], cfg["spp"], cfg["depth"]
+    scene_host = host.create_random_world(1, cfg["grid"], cfg.get("diffuse_below", 0.8),
+                                          cfg.get("metal_below", 0.95), cfg.get("glass", False))
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, W / H)
+    scene = hip.Scene(scene_host.spheres, scene_host.materials)   # resident in HBM from here on
+    frame = hip.make_frame(camera.m, W, H, spp, depth, args.seed, flags=0)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    plan = multi_gpu.RowPlan(W, H, world)
+    sharded = multi_gpu.ShardedFrame(plan, device, rank)
+    full = torch.zeros((H, W, 3), dtype=torch.float32, device=device) if world == 1 else None
+
+    def render_fn(tiles, offs, strides, out):
+        hip.render_device_async(scene, frame, tiles, offs, strides, True, out.data_ptr(), stream)
+
+    def step():
+        if world == 1:
+            hip.render_rows_device_async(scene, frame, 0, H, True, full.data_ptr(), stream)
+            return full
+        return sharded.render_and_gather(render_fn)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fb = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    launch_ms = hip.get_launch_ms(min(args.steps, 64))
+    st = hip.get_stats()                       # this rank's last launch
+    kernel_ms = float(launch_ms.mean()) if len(launch_ms) else float("nan")
+    n_spheres = len(scene_host.spheres)
+    flop = FLOP_PER_TEST * n_spheres * st.rays
+    achieved = flop / (kernel_ms * 1e-3) * 1e-12 if kernel_ms > 0 else 0.0
+
+    if rank == 0:
+        samples_per_step = W * H * spp
+        value = samples_per_step * args.steps / elapsed * 1e-6
+        line = {
+            "metric": "Msamples/sec at 1080p RTIOW final scene" if args.config == DEFAULT_CONFIG
+                      else "Msamples/sec, " + args.config,
+            "value": round(value, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": args.config,
+                "spheres": n_spheres,
+                "image": "%dx%d" % (W, H),
+                "samples_per_pixel": spp,
+                "max_depth": depth,
+                "sharding": "rows in blocks of %d dealt round-robin over %d rank(s)%s"
+                            % (plan.block_rows, world, ", RCCL gather to rank 0" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "valu_fp32",
+                "achieved": round(achieved, 3),
+                "peak": PEAK_FP32_VALU_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+                "traffic": None,
+                "kernel": "rt::trace_kernel<false,%s>" % ("true" if n_spheres > 2048 else "false"),
+                "kernel_ms": round(kernel_ms, 3),
+                "rays_per_launch": int(st.rays),
+                "rays_per_sample": round(st.rays / max(st.samples, 1), 4),
+                "flop_per_ray_sphere_test": FLOP_PER_TEST,
+                "rank": 0,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.seed)
+        else:
+            line["cpu_baseline"] = None
+        if fb is not None:
+            import numpy as np
+            img = fb.detach().cpu().numpy()
+            line["config"]["mean_rgb"] = [round(float(v), 5) for v in np.nanmean(img, axis=(0, 1))]
+        print(json.dumps(line), flush=True)
+
+    scene.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

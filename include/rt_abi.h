@@ -132,7 +132,7 @@ typedef struct rt_ray_in {
 #define RT_KIND_METAL 2u
 #define RT_KIND_DIELECTRIC 3u
 typedef struct rt_ray_out {
-  uint32_t hit;          /* 0 = miss (then sky[] holds the background colour) */
+  uint32_t hit;          /* 0 = miss (then ar,ag,ab hold the background colour) */
   uint32_t sphere;       /* index of the closest sphere */
   uint32_t material;
   uint32_t kind;         /* RT_KIND_* */
@@ -215,6 +215,12 @@ int rt_get_stats(rt_stats* out);
  * number of values written, or a negative rt_status.  The counterpart in the reference is the
  * Instant::now()/elapsed() pair around the tile loop (src/cpu/multi.rs:146,163). */
 int rt_get_launch_ms(uint32_t n_last, float* out_ms);
+
+/* Diagnostic: wave-cycles the last launch spent per phase of its main loop, as
+ * out8[0..4] = {refill, scan, replay, shade, steps}.  All zero unless the library was built
+ * with -DRT_DIAG_PHASES (a build for reading shares; its stamps slow the kernel down).
+ * No counterpart in the reference. */
+int rt_get_phase_cycles(uint64_t* out8);
 
 /* ---- test hook --------------------------------------------------------------------------- */
 

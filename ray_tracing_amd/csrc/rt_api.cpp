@@ -57,6 +57,7 @@ struct State {
   rt::Counters* counters = nullptr;       // device
   rt::TileDev* tiles = nullptr;           // device, grow-only
   size_t tiles_cap = 0;
+  std::vector<rt::TileDev> tiles_host;    // what g.tiles currently holds
   float* partial = nullptr;               // device, grow-only: per-slice sums
   size_t partial_cap = 0;                 // in floats
   hipEvent_t ev_begin[kEventRing], ev_end[kEventRing];
@@ -83,14 +84,24 @@ int check_frame(const rt_frame* f) {
   return RT_OK;
 }
 
-// Lanes that share one pixel's samples.  A function of the FULL image and spp only, so a
-// frame gives the same sums whatever part of it a call renders.
+// Work items per pixel.  One pixel's samples are cut into `slices` contiguous runs, each an
+// independent work item whose sum lands in its own plane of a partial buffer; a second kernel
+// adds the planes in slice order.  Two reasons to cut:
+//  * granularity: a path at max_depth 50 inside glass can cost 20x the average, and a lane
+//    runs its item to the end while the frame's last items drain, so an item must be a small
+//    fraction of the frame (about kSamplesPerItem samples);
+//  * small images: fewer pixels than lanes.
+// The count is a function of the FULL image and spp only, so a frame gives the same sums
+// whatever part of it a call renders and however many GPUs share it.
 uint32_t choose_slices(const rt_frame& f) {
   if (f.flags & RT_FLAG_SEQUENTIAL_SUM) return 1;
   const uint64_t pixels = (uint64_t)f.image_width * f.image_height;
-  if (pixels >= rt::kTargetItems) return 1;
-  uint64_t s = (rt::kTargetItems + pixels - 1) / pixels;
-  if (s > f.samples_per_pixel) s = f.samples_per_pixel;
+  const uint64_t spp = f.samples_per_pixel;
+  uint64_t by_grain = (spp + rt::kSamplesPerItem - 1) / rt::kSamplesPerItem;
+  if (by_grain > rt::kMaxGrainSlices) by_grain = rt::kMaxGrainSlices;
+  uint64_t by_fill = pixels >= rt::kTargetItems ? 1 : (rt::kTargetItems + pixels - 1) / pixels;
+  uint64_t s = by_grain > by_fill ? by_grain : by_fill;
+  if (s > spp) s = spp;
   if (s > 64) s = 64;
   return (uint32_t)s;
 }
@@ -145,18 +156,24 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
     p.tile0 = tiles[0];
     p.tiles = nullptr;
   } else {
-    if (tiles.size() > g.tiles_cap) {
-      RT_HIP(hipStreamSynchronize(stream));
-      if (g.tiles) RT_HIP(hipFree(g.tiles));
-      g.tiles = nullptr;
-      g.tiles_cap = 0;
-      RT_HIP(hipMalloc((void**)&g.tiles, tiles.size() * sizeof(rt::TileDev)));
-      g.tiles_cap = tiles.size();
+    // The table lives in one grow-only device buffer.  A caller that renders the same tile
+    // list frame after frame (a rank's row blocks) pays for the upload once.
+    const bool same = g.tiles_host.size() == tiles.size() &&
+                      memcmp(g.tiles_host.data(), tiles.data(), tiles.size() * sizeof(rt::TileDev)) == 0;
+    if (!same) {
+      RT_HIP(hipDeviceSynchronize());   // an earlier launch, on any stream, may still read it
+      if (tiles.size() > g.tiles_cap) {
+        if (g.tiles) RT_HIP(hipFree(g.tiles));
+        g.tiles = nullptr;
+        g.tiles_cap = 0;
+        g.tiles_host.clear();
+        RT_HIP(hipMalloc((void**)&g.tiles, tiles.size() * sizeof(rt::TileDev)));
+        g.tiles_cap = tiles.size();
+      }
+      RT_HIP(hipMemcpy(g.tiles, tiles.data(), tiles.size() * sizeof(rt::TileDev),
+                       hipMemcpyHostToDevice));
+      g.tiles_host = tiles;
     }
-    // the previous launch may still be reading the table
-    RT_HIP(hipStreamSynchronize(stream));
-    RT_HIP(hipMemcpy(g.tiles, tiles.data(), tiles.size() * sizeof(rt::TileDev),
-                     hipMemcpyHostToDevice));
     p.tiles = g.tiles;
   }
 
@@ -164,7 +181,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   if (p.slices > 1) {
     const size_t need = (size_t)out_pixels * 3 * p.slices;
     if (need > g.partial_cap) {
-      RT_HIP(hipStreamSynchronize(stream));
+      RT_HIP(hipDeviceSynchronize());
       if (g.partial) RT_HIP(hipFree(g.partial));
       g.partial = nullptr;
       g.partial_cap = 0;
@@ -390,6 +407,7 @@ int rt_render_device_async(const rt_scene* scene, const rt_frame* frame, const r
       return fail(RT_ERR_INVALID_ARGUMENT, "tile %u: out_stride %u < width %u", i, out_stride[i],
                   tiles[i].width);
     rt::TileDev t;
+    memset(&t, 0, sizeof t);
     t.x = tiles[i].x; t.y = tiles[i].y; t.w = tiles[i].width; t.h = tiles[i].height;
     t.first_pixel = (uint32_t)first;
     t.out_stride = out_stride[i];
@@ -414,6 +432,7 @@ int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame, ui
   if (row_begin == row_end) return RT_OK;
   if (!d_out) return fail(RT_ERR_INVALID_ARGUMENT, "d_out is NULL");
   rt::TileDev t;
+  memset(&t, 0, sizeof t);
   t.x = 0; t.y = row_begin; t.w = frame->image_width; t.h = row_end - row_begin;
   t.first_pixel = 0;
   t.out_stride = frame->image_width;
@@ -446,6 +465,16 @@ int rt_get_stats(rt_stats* out) {
     s.kernel_ms = ms;
   }
   *out = s;
+  return RT_OK;
+}
+
+int rt_get_phase_cycles(uint64_t* out8) {
+  if (int rc = check_ready()) return rc;
+  if (!out8) return fail(RT_ERR_INVALID_ARGUMENT, "out8 is NULL");
+  RT_HIP(hipStreamSynchronize(g.last_stream ? g.last_stream : g.stream));
+  rt::Counters c;
+  RT_HIP(hipMemcpy(&c, g.counters, sizeof c, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; ++i) out8[i] = c.phase[i];
   return RT_OK;
 }
 

@@ -18,6 +18,8 @@ constexpr uint32_t kChunkSpheres = 2048; // sphere records resident in LDS at a 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic
 constexpr uint32_t kTargetItems = 1u << 20; // below this many pixels, split samples over lanes
+constexpr uint32_t kSamplesPerItem = 8;     // samples one work item runs (tail granularity)
+constexpr uint32_t kMaxGrainSlices = 16;    // cap on slices chosen for granularity alone
 
 // One tile of the request as the kernel sees it.
 struct TileDev {
@@ -44,6 +46,9 @@ struct Counters {
   uint32_t pad;
   unsigned long long rays;     // World::hit calls
   unsigned long long samples;  // shoot_ray calls from the pixel loop
+  // Wave-cycles per phase (refill, scan, replay, shade, steps); filled only by a build with
+  // -DRT_DIAG_PHASES, whose timings are for shares, not for speed.
+  unsigned long long phase[8];
 };
 
 struct TraceParams {

@@ -39,8 +39,23 @@
 
 #include "../../include/rt_rng.h"
 
+#ifdef RT_DIAG_PHASES
+#define RT_STAMP(acc, t0)                                                   \
+  do {                                                                      \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();           \
+    (acc) += now_ - (t0);                                                   \
+    (t0) = now_;                                                            \
+  } while (0)
+#else
+#define RT_STAMP(acc, t0) do { } while (0)
+#endif
+
 namespace rt {
 namespace {
+
+struct PhaseClock {
+  unsigned long long t0, refill, scan, replay, shade, steps;
+};
 
 constexpr int R = kRaysPerLane;
 constexpr int Q = kQueueSlots;
@@ -284,7 +299,8 @@ __device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, ui
 // Scan one LDS-resident chunk of `cn` spheres for all paths of the wave.
 template <bool STRICT>
 __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, uint32_t cn,
-                                           uint32_t chunk_base, uint16_t* q, uint32_t lane) {
+                                           uint32_t chunk_base, uint16_t* q, uint32_t lane,
+                                           PhaseClock& clk) {
   uint32_t i = 0;
   while (i < cn) {
     bool flush = false;
@@ -298,7 +314,9 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, uint
     if (!flush) {
       for (; i < cn; ++i) test_sphere<STRICT>(sph[i], i, P, q, lane, flush);
     }
+    RT_STAMP(clk.scan, clk.t0);
     replay_queue(P, sph, chunk_base, q, lane);
+    RT_STAMP(clk.replay, clk.t0);
   }
 }
 
@@ -441,6 +459,10 @@ __global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
   uint32_t grab_next = 0, grab_end = 0;
   bool exhausted = false;
   uint32_t n_rays = 0, n_samples = 0;
+  PhaseClock clk = {0, 0, 0, 0, 0, 0};
+#ifdef RT_DIAG_PHASES
+  clk.t0 = __builtin_amdgcn_s_memtime();
+#endif
 
   for (;;) {
     // ---- refill: next sample of the item, or the next item ------------------------------
@@ -468,6 +490,9 @@ __global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
       if (!wave_alive) break;
     }
 
+    RT_STAMP(clk.refill, clk.t0);
+    clk.steps++;
+
     // ---- World::hit --------------------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -481,10 +506,10 @@ __global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
         __syncthreads();   // every wave is done with the previous chunk
         for (uint32_t i = threadIdx.x; i < cn; i += kThreads) sph[i] = p.scene.geom[base + i];
         __syncthreads();
-        scan_chunk<STRICT>(P, sph, cn, base, q, lane);
+        scan_chunk<STRICT>(P, sph, cn, base, q, lane, clk);
       }
     } else {
-      scan_chunk<STRICT>(P, sph, n, 0, q, lane);
+      scan_chunk<STRICT>(P, sph, n, 0, q, lane, clk);
     }
 
     // ---- the rest of shoot_ray's body ----------------------------------------------------
@@ -520,8 +545,18 @@ __global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
         }
       }
     }
+    RT_STAMP(clk.shade, clk.t0);
   }
 
+#ifdef RT_DIAG_PHASES
+  if (lane == 0) {
+    atomicAdd(&p.counters->phase[0], clk.refill);
+    atomicAdd(&p.counters->phase[1], clk.scan);
+    atomicAdd(&p.counters->phase[2], clk.replay);
+    atomicAdd(&p.counters->phase[3], clk.shade);
+    atomicAdd(&p.counters->phase[4], clk.steps);
+  }
+#endif
   const unsigned long long rays = wave_sum(n_rays);
   const unsigned long long samples = wave_sum(n_samples);
   if (lane == 0) {
@@ -578,7 +613,8 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < cn; k += kThreads) sph[k] = p.scene.geom[base + k];
     __syncthreads();
-    scan_chunk<STRICT>(P, sph, cn, base, q, lane);
+    PhaseClock clk = {0, 0, 0, 0, 0, 0};
+    scan_chunk<STRICT>(P, sph, cn, base, q, lane, clk);
   }
   if (!live) return;
 

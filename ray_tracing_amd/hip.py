@@ -14,7 +14,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_hip.so")
+# RT_HIP_LIB lets a developer point at a diagnostic build of the same library.
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 
 # every symbol include/rt_abi.h declares
 EXPORTS = (
@@ -22,7 +23,7 @@ EXPORTS = (
     "rt_render", "rt_render_tiles", "rt_compose",
     "rt_scene_create", "rt_scene_destroy",
     "rt_render_device_async", "rt_render_rows_device_async",
-    "rt_synchronize", "rt_get_stats", "rt_get_launch_ms", "rt_trace_rays",
+    "rt_synchronize", "rt_get_stats", "rt_get_launch_ms", "rt_get_phase_cycles", "rt_trace_rays",
 )
 
 
@@ -83,6 +84,7 @@ def lib():
     L.rt_get_stats.argtypes = [C.POINTER(abi.RtStats)]
     L.rt_get_launch_ms.argtypes = [u32, vp]
     L.rt_get_launch_ms.restype = i
+    L.rt_get_phase_cycles.argtypes = [vp]
     L.rt_trace_rays.argtypes = [vp, vp, u32, u32, u32, vp]
     _lib = L
     return L
@@ -214,6 +216,12 @@ def get_launch_ms(n_last):
     if got < 0:
         check(got)
     return out[:got]
+
+
+def get_phase_cycles():
+    out = np.zeros(8, dtype=np.uint64)
+    check(lib().rt_get_phase_cycles(abi.ptr(out)))
+    return out
 
 
 def trace_rays(scene, rays, seed, flags=0):

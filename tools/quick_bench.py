@@ -44,6 +44,13 @@ def main():
               % (len(s), w, h, spp, flags, ms, st.samples / ms * 1e-3, st.rays / max(st.samples, 1),
                  st.sphere_tests / ms * 1e-6, tflops, 100 * tflops / PEAK_TFLOPS, PEAK_TFLOPS,
                  st.workgroups, st.threads_per_workgroup, st.slices), flush=True)
+    ph = hip.get_phase_cycles().astype(np.float64)
+    if ph[:4].sum() > 0:
+        tot = ph[:4].sum()
+        print("phase shares: refill %.1f%%  scan %.1f%%  replay %.1f%%  shade %.1f%%   "
+              "cycles/step/wave %.0f (steps %d)" % (100 * ph[0] / tot, 100 * ph[1] / tot,
+                                                   100 * ph[2] / tot, 100 * ph[3] / tot,
+                                                   tot / max(ph[4], 1), int(ph[4])))
     img = out.cpu().numpy()
     print("mean rgb", np.nanmean(img, axis=(0, 1)), "nan px", int(np.isnan(img).any(axis=2).sum()))
 
