@@ -19,6 +19,7 @@
 
 struct rt_scene {
   rt::SceneDev dev;
+  void* trig = nullptr;
   void* geom = nullptr;
   void* aux = nullptr;
   void* mat = nullptr;
@@ -66,6 +67,28 @@ struct State {
   hipStream_t last_stream = nullptr;
 };
 State g;
+
+// Per-sphere constant of the kernel's conservative discriminant scan.
+//
+// The scan decides which spheres get the reference's exact Sphere::hit arithmetic.  It evaluates
+//     disc' = hb'^2 - c',   hb' = o.dn - c.dn,   c' = k' - 2 o.c + |o|^2 (1 - 2^-17)
+// with dn = d/|d| (slightly lengthened), i.e. the reference's discriminant divided by |d|^2 and
+// expanded so that no o - c subtraction is needed (8 instead of 11 vector instructions).  The
+// expansion rounds differently from src/main.rs:131-135, so k' carries a slack that makes the
+// scan CONSERVATIVE: with u = 2^-24, the reference's computed discriminant is within
+// 22u |d|^2 (|o-c|^2 + r^2) of the exact one and the scan's within 24.3u (|o|+|c|)^2 + 4u r^2, so
+// any slack >= 93u (|o|^2 + |c|^2) + 26u r^2 guarantees that a sphere whose reference discriminant
+// is not negative is never skipped.  The kernel takes 2^-17 |o|^2 off per ray; here
+// 2^-17 |c|^2 + 2^-19 r^2 comes off per sphere.  False positives only cost a replay.
+// Computed in double and rounded toward -infinity.
+float trigger_constant(const rt_sphere& s) {
+  const double c2 = (double)s.x * s.x + (double)s.y * s.y + (double)s.z * s.z;
+  const double r2 = (double)s.radius * (double)s.radius;
+  const double k = c2 - r2 - std::ldexp(c2, -17) - std::ldexp(r2, -19);
+  float kf = (float)k;
+  if ((double)kf > k) kf = std::nextafterf(kf, -INFINITY);
+  return kf;
+}
 
 int check_ready() {
   if (!g.ready) return fail(RT_ERR_NOT_INITIALIZED, "rt_init() has not been called");
@@ -336,12 +359,20 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
   if ((n_spheres && !spheres) || (n_materials && !materials))
     return fail(RT_ERR_INVALID_ARGUMENT, "NULL scene arrays");
   if (n_spheres > (1u << 24)) return fail(RT_ERR_LIMIT, "more than 2^24 spheres");
-  for (uint32_t i = 0; i < n_spheres; ++i)
+  for (uint32_t i = 0; i < n_spheres; ++i) {
     if (spheres[i].material_id >= n_materials)
       return fail(RT_ERR_INVALID_ARGUMENT, "sphere %u names material %u of %u", i,
                   spheres[i].material_id, n_materials);
+    // |c|^2 and r^2 must be finite f32 values for the discriminant scan
+    const rt_sphere& sp = spheres[i];
+    const double mag = (double)sp.x * sp.x + (double)sp.y * sp.y + (double)sp.z * sp.z +
+                       (double)sp.radius * sp.radius;
+    if (!(mag < 1e37))
+      return fail(RT_ERR_LIMIT, "sphere %u: centre or radius not finite or beyond 1e18", i);
+  }
   RT_HIP(hipSetDevice(g.device));
 
+  std::vector<float4> trig(n_spheres ? n_spheres : 1);
   std::vector<float4> geom(n_spheres ? n_spheres : 1);
   std::vector<float2> aux(n_spheres ? n_spheres : 1);
   std::vector<float4> mat(n_materials ? 2 * (size_t)n_materials : 2);
@@ -349,6 +380,7 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
     const rt_sphere& s = spheres[i];
     volatile float r2 = s.radius * s.radius;   // `self.radius * self.radius`, src/main.rs:134
     geom[i] = make_float4(s.x, s.y, s.z, r2);
+    trig[i] = make_float4(s.x, s.y, s.z, trigger_constant(s));
     float idbits;
     memcpy(&idbits, &s.material_id, sizeof idbits);
     aux[i] = make_float2(s.radius, idbits);
@@ -363,6 +395,9 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
   s->device = g.device;
   ScopedScene guard;
   guard.s = s;
+  RT_HIP(hipMalloc(&s->trig, trig.size() * sizeof(float4)));
+  RT_HIP(hipMemcpy(s->trig, trig.data(), trig.size() * sizeof(float4), hipMemcpyHostToDevice));
+  s->dev.trig = (const float4*)s->trig;
   RT_HIP(hipMalloc(&s->geom, geom.size() * sizeof(float4)));
   RT_HIP(hipMalloc(&s->aux, aux.size() * sizeof(float2)));
   RT_HIP(hipMalloc(&s->mat, mat.size() * sizeof(float4)));
@@ -381,6 +416,7 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
 
 int rt_scene_destroy(rt_scene* scene) {
   if (!scene) return RT_OK;
+  if (scene->trig) (void)hipFree(scene->trig);
   if (scene->geom) (void)hipFree(scene->geom);
   if (scene->aux) (void)hipFree(scene->aux);
   if (scene->mat) (void)hipFree(scene->mat);

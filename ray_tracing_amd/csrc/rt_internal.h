@@ -30,10 +30,13 @@ struct TileDev {
 };
 
 // Device copy of a World (reference src/main.rs:168-172), split hot/cold:
-//   geom[i] = (cx, cy, cz, radius*radius)       read by every ray for every sphere
+//   trig[i] = (cx, cy, cz, k')                  read by every ray for every sphere; k' is
+//             |c|^2 - r^2 minus a rounding slack (see trigger_constant in rt_api.cpp)
+//   geom[i] = (cx, cy, cz, radius*radius)       read when a sphere is replayed exactly
 //   aux[i]  = (radius, material_id bits)        read once per hit
 //   mat[2m] = (r, g, b, flags bits), mat[2m+1] = (metallic_strength, ir, 0, 0)
 struct SceneDev {
+  const float4* trig;
   const float4* geom;
   const float2* aux;
   const float4* mat;

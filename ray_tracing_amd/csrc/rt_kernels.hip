@@ -16,20 +16,23 @@
 //    wave: at max_depth 50 this is what keeps the vector ALU busy.
 //  * The recursion of shoot_ray is a loop with a running throughput; random numbers are drawn
 //    in the reference's order from the counter stream of rt_rng.h.
-//  * World::hit is split in two.  The scan evaluates, for every sphere, only the discriminant
-//    half_b^2 - a*c (11 VALU instructions with fused multiply-adds for the 17 flops of
-//    src/main.rs:131-135); the sphere record (cx,cy,cz,r^2) is one wave-uniform 16-byte LDS
-//    read shared by both paths of every lane.  A sphere whose discriminant is not negative is
-//    appended to a small per-path queue in LDS.  After the scan each lane replays its own
-//    queue through the reference's exact Sphere::hit arithmetic (IEEE sqrt and divide, no
-//    contraction) in storage order, so the closest-hit decision and t are the reference's.
-//    Replaying per lane keeps all 64 lanes busy in the slow part instead of one lane per
-//    triggering sphere.
+//  * World::hit is split in two.  The scan evaluates, for every sphere, only the sign of the
+//    discriminant half_b^2 - a*c of src/main.rs:131-135 (17 flops as written there).  It does so
+//    on an expanded, pre-normalised form, hb' = o.dn - c.dn and c' = k' - 2 o.c + |o|^2, which
+//    needs no o - c subtraction: 8 fused VALU instructions per ray/sphere pair.  The sphere
+//    record (cx,cy,cz,k') is one wave-uniform 16-byte LDS read shared by both paths of every
+//    lane.  k' and |o|^2 carry a slack that bounds the rounding of both forms, so the scan never
+//    skips a sphere the reference's own arithmetic would accept (derivation: trigger_constant in
+//    rt_api.cpp).  A sphere that passes is appended to a small per-path queue in LDS.  After
+//    the scan each lane replays its own queue through the reference's exact Sphere::hit
+//    arithmetic (IEEE sqrt and divide, no contraction) in storage order, so the closest-hit
+//    decision and t are bit-for-bit the reference's.  Replaying per lane keeps all 64 lanes
+//    busy in the slow part instead of one lane per triggering sphere.
 //  * Scenes larger than kChunkSpheres are streamed through the same LDS buffer chunk by chunk
 //    by the whole workgroup (MULTI = true), carrying closest-hit across chunks.
-//  * STRICT = true evaluates the discriminant in the reference's operation order without
-//    fused multiply-adds (17 instructions); every hit decision is then bit-identical to the
-//    CPU restatement.  STRICT = false differs only for rays within rounding of tangency.
+//  * STRICT = true makes the scan evaluate the discriminant literally, in the reference's
+//    operation order without fused multiply-adds (17 instructions).  Both modes give the same
+//    bits; STRICT exists to check the conservative scan against the literal one.
 //
 // Build flags that matter: -ffp-contract=off (every fma below is written out by hand),
 // -fno-slp-vectorize (auto-packing into v_pk_*_f32 costs more shuffles than it saves here).
@@ -224,12 +227,33 @@ __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, floa
   return b;
 }
 
+// Sphere records the LDS buffer holds: the whole scene, or one chunk.  Rounded up to a
+// multiple of 4 so that the radius^2 array behind the records stays 16-byte aligned.
+__host__ __device__ __forceinline__ uint32_t lds_capacity(uint32_t n_spheres) {
+  const uint32_t cap = n_spheres > kChunkSpheres ? kChunkSpheres : n_spheres;
+  return (cap + 3u) & ~3u;
+}
+
+// Workgroup-cooperative copy of spheres [base, base+cn) into LDS.
+__device__ __forceinline__ void stage_chunk(const SceneDev& sc, uint32_t base, uint32_t cn,
+                                            float4* sph, float* sr2) {
+  for (uint32_t i = threadIdx.x; i < cn; i += kThreads) {
+    sph[i] = sc.trig[base + i];
+    sr2[i] = sc.geom[base + i].w;
+  }
+}
+
 // ---- per-path state -------------------------------------------------------------------------
 struct Path {
   // current segment
   float ox, oy, oz;
   float dx, dy, dz;
   float a;          // dir.length_squared(), src/main.rs:132
+  // constants of the conservative scan for this segment (prep_segment)
+  float ndx, ndy, ndz;   // -d / |d|, lengthened by 2^-20
+  float od;              // o . (d / |d|)
+  float o2x, o2y, o2z;   // -2 o
+  float oo;              // |o|^2 (1 - 2^-17)
   float closest;
   uint32_t best;
   uint32_t cnt;     // queued candidates
@@ -247,41 +271,101 @@ struct Path {
   uint32_t sample, sample_end;
 };
 
-// Append to / replay the deferred-candidate queue.  Layout: q[(r*Q + slot)*64 + lane], u16,
-// holding indices local to the sphere chunk resident in LDS.
-template <bool STRICT>
-__device__ __forceinline__ void test_sphere(const float4 s, uint32_t local_index, Path (&P)[R],
-                                            uint16_t* q, uint32_t lane, bool& flush) {
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const float ocx = P[r].ox - s.x, ocy = P[r].oy - s.y, ocz = P[r].oz - s.z;
-    float disc;
-    if (STRICT) {
-      const float half_b = (ocx * P[r].dx + ocy * P[r].dy) + ocz * P[r].dz;
-      const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - s.w;
-      disc = half_b * half_b - P[r].a * c;
-    } else {
-      const float half_b =
-          __builtin_fmaf(ocz, P[r].dz, __builtin_fmaf(ocy, P[r].dy, ocx * P[r].dx));
-      const float c = __builtin_fmaf(
-          ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, -s.w)));
-      disc = __builtin_fmaf(half_b, half_b, -(P[r].a * c));
-    }
-    const bool trig = !(disc < 0.0f);   // the reference returns early on `discriminant < 0.0`
-    if (__builtin_amdgcn_ballot_w64(trig) != 0) {   // wave-uniform: skipped for most spheres
-      if (trig && P[r].alive) {
-        q[(r * Q + P[r].cnt) * kWave + lane] = (uint16_t)local_index;
-        P[r].cnt++;
-      }
-      // A block of U spheres can add at most U entries per path: ask for a replay while
-      // every queue still has room for the rest of this block and the next one.
-      if (__builtin_amdgcn_ballot_w64(P[r].cnt >= (uint32_t)(Q - U)) != 0) flush = true;
-    }
+// Constants of the conservative scan for the segment now in (o, d, a).
+__device__ __forceinline__ void prep_segment(Path& P) {
+  // 1/|d|: v_rsq_f32 is good to 1 ulp; lengthening dn by 2^-20 keeps hb'^2 from coming out low.
+  const float s = __builtin_amdgcn_rsqf(P.a) * 1.00000095367431640625f;
+  const float dnx = P.dx * s, dny = P.dy * s, dnz = P.dz * s;
+  P.ndx = -dnx; P.ndy = -dny; P.ndz = -dnz;
+  P.od = __builtin_fmaf(P.oz, dnz, __builtin_fmaf(P.oy, dny, P.ox * dnx));
+  P.o2x = -2.0f * P.ox; P.o2y = -2.0f * P.oy; P.o2z = -2.0f * P.oz;
+  const float oo = P.ox * P.ox + P.oy * P.oy + P.oz * P.oz;
+  P.oo = oo * 0.99999237060546875f;   // 1 - 2^-17
+  // A direction of zero, infinite or NaN length, or an origin that is not finite: the scan's
+  // algebra does not apply, so make it pass every sphere on to the exact arithmetic (which
+  // then does whatever the reference does with such a ray).  hb' = +inf, c' = -inf.
+  const float inf = __builtin_inff();
+  if (!(P.a > 0.0f) || !(P.a < inf) || !(oo < inf) || !(__builtin_fabsf(P.od) < inf)) {
+    P.ndx = P.ndy = P.ndz = 0.0f;
+    P.o2x = P.o2y = P.o2z = 0.0f;
+    P.od = inf;
+    P.oo = -inf;
   }
 }
 
-__device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, uint32_t chunk_base,
-                                             const uint16_t* q, uint32_t lane) {
+// NB spheres against the R paths of the lane.  `s[u]` = (cx, cy, cz, k'), `r2[u]` = radius^2
+// (only read when STRICT).  All NB*R discriminants are evaluated first, as independent
+// instruction chains; their sign bits are folded with an integer max (a float with the sign
+// bit clear, NaN included, is a non-negative int) and ONE rarely-taken branch per block leads
+// to the code that queues the candidates: q[(r*Q + slot)*64 + lane] (u16, indices local to the
+// sphere chunk resident in LDS), in storage order per path.
+template <bool STRICT, int NB>
+__device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&r2)[NB],
+                                           uint32_t first_index, Path (&P)[R], uint16_t* q,
+                                           uint32_t lane, bool& flush) {
+  float disc[NB][R];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (STRICT) {   // src/main.rs:131-135, literally
+        const float ocx = P[r].ox - s[u].x, ocy = P[r].oy - s[u].y, ocz = P[r].oz - s[u].z;
+        const float half_b = (ocx * P[r].dx + ocy * P[r].dy) + ocz * P[r].dz;
+        const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2[u];
+        disc[u][r] = half_b * half_b - P[r].a * c;
+      } else {        // conservative expanded form, 8 instructions
+        const float hb = __builtin_fmaf(s[u].z, P[r].ndz,
+                         __builtin_fmaf(s[u].y, P[r].ndy, __builtin_fmaf(s[u].x, P[r].ndx, P[r].od)));
+        const float cp = __builtin_fmaf(s[u].z, P[r].o2z,
+                         __builtin_fmaf(s[u].y, P[r].o2y, __builtin_fmaf(s[u].x, P[r].o2x, s[u].w)));
+        disc[u][r] = __builtin_fmaf(hb, hb, -(cp + P[r].oo));
+      }
+    }
+  }
+  bool any;
+  if (STRICT) {
+    // literal mode keeps the float comparison: a discriminant that is NaN of either sign, or
+    // -0.0, is "not less than zero" in the reference
+    any = false;
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) any = any || !(disc[u][r] < 0.0f);
+  } else {
+    // prep_segment keeps NaN out of the per-ray constants and rt_scene_create keeps it out of
+    // the records, and a fused multiply-add cannot produce -0.0 here, so "sign bit clear" is
+    // exactly "not less than zero"
+    int m = (int)0x80000000;
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) m = max(m, __float_as_int(disc[u][r]));
+    any = m >= 0;
+  }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool trig = !(disc[u][r] < 0.0f);   // `if discriminant < 0.0 { return false }`
+        if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+          if (trig && P[r].alive) {
+            q[(r * Q + P[r].cnt) * kWave + lane] = (uint16_t)(first_index + u);
+            P[r].cnt++;
+          }
+        }
+      }
+    }
+    // A block of U spheres adds at most U entries per path: ask for a replay while every
+    // queue still has room for the next block.
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (__builtin_amdgcn_ballot_w64(P[r].cnt >= (uint32_t)(Q - U)) != 0) flush = true;
+  }
+}
+
+__device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, const float* sr2,
+                                             uint32_t chunk_base, const uint16_t* q, uint32_t lane) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t n = P[r].cnt;
@@ -289,7 +373,9 @@ __device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, ui
     for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0; ++k) {
       if (k < n) {
         const uint32_t li = q[(r * Q + k) * kWave + lane];
-        exact_hit(sph[li], chunk_base + li, o, d, P[r].a, P[r].closest, P[r].best);
+        float4 rec = sph[li];
+        rec.w = sr2[li];
+        exact_hit(rec, chunk_base + li, o, d, P[r].a, P[r].closest, P[r].best);
       }
     }
     P[r].cnt = 0;
@@ -298,24 +384,31 @@ __device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, ui
 
 // Scan one LDS-resident chunk of `cn` spheres for all paths of the wave.
 template <bool STRICT>
-__device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, uint32_t cn,
-                                           uint32_t chunk_base, uint16_t* q, uint32_t lane,
-                                           PhaseClock& clk) {
+__device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, const float* sr2,
+                                           uint32_t cn, uint32_t chunk_base, uint16_t* q,
+                                           uint32_t lane, PhaseClock& clk) {
   uint32_t i = 0;
   while (i < cn) {
     bool flush = false;
     for (; i + U <= cn && !flush; i += U) {
       float4 s[U];
+      float r2[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) s[u] = sph[i + u];
-#pragma unroll
-      for (int u = 0; u < U; ++u) test_sphere<STRICT>(s[u], i + u, P, q, lane, flush);
+      for (int u = 0; u < U; ++u) {
+        s[u] = sph[i + u];
+        r2[u] = STRICT ? sr2[i + u] : 0.0f;
+      }
+      test_block<STRICT, U>(s, r2, i, P, q, lane, flush);
     }
     if (!flush) {
-      for (; i < cn; ++i) test_sphere<STRICT>(sph[i], i, P, q, lane, flush);
+      for (; i < cn; ++i) {
+        const float4 s1[1] = {sph[i]};
+        const float r1[1] = {STRICT ? sr2[i] : 0.0f};
+        test_block<STRICT, 1>(s1, r1, i, P, q, lane, flush);
+      }
     }
     RT_STAMP(clk.scan, clk.t0);
-    replay_queue(P, sph, chunk_base, q, lane);
+    replay_queue(P, sph, sr2, chunk_base, q, lane);
     RT_STAMP(clk.replay, clk.t0);
   }
 }
@@ -404,6 +497,7 @@ __device__ __forceinline__ void start_sample(Path& P, const TraceParams& p) {
   P.ox = p.origin[0]; P.oy = p.origin[1]; P.oz = p.origin[2];
   P.dx = dir.x; P.dy = dir.y; P.dz = dir.z;
   P.a = dot(dir, dir);
+  prep_segment(P);
   P.tr = P.tg = P.tb = 1.0f;
   P.depth = p.max_depth;
   P.alive = true;
@@ -431,15 +525,16 @@ template <bool STRICT, bool MULTI>
 __global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
   extern __shared__ float4 lds[];
   const uint32_t n = p.scene.n_spheres;
-  const uint32_t cap = MULTI ? kChunkSpheres : n;
-  float4* sph = lds;
-  uint16_t* qall = reinterpret_cast<uint16_t*>(lds + cap);
+  const uint32_t cap = lds_capacity(n);
+  float4* sph = lds;                                       // (cx, cy, cz, k') per sphere
+  float* sr2 = reinterpret_cast<float*>(lds + cap);        // radius^2 per sphere
+  uint16_t* qall = reinterpret_cast<uint16_t*>(sr2 + cap);
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = threadIdx.x / kWave;
   uint16_t* q = qall + wave * (R * Q * kWave);
 
   if (!MULTI) {
-    for (uint32_t i = threadIdx.x; i < n; i += kThreads) sph[i] = p.scene.geom[i];
+    stage_chunk(p.scene, 0, n, sph, sr2);
     __syncthreads();
   }
 
@@ -453,6 +548,7 @@ __global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
     P[r].ox = P[r].oy = P[r].oz = 0.0f;
     P[r].dx = P[r].dy = P[r].dz = 0.0f;
     P[r].a = 1.0f;
+    prep_segment(P[r]);
     P[r].closest = kTMax;
     P[r].best = kNone;
   }
@@ -504,12 +600,12 @@ __global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
       for (uint32_t base = 0; base < n; base += kChunkSpheres) {
         const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
         __syncthreads();   // every wave is done with the previous chunk
-        for (uint32_t i = threadIdx.x; i < cn; i += kThreads) sph[i] = p.scene.geom[base + i];
+        stage_chunk(p.scene, base, cn, sph, sr2);
         __syncthreads();
-        scan_chunk<STRICT>(P, sph, cn, base, q, lane, clk);
+        scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
       }
     } else {
-      scan_chunk<STRICT>(P, sph, n, 0, q, lane, clk);
+      scan_chunk<STRICT>(P, sph, sr2, n, 0, q, lane, clk);
     }
 
     // ---- the rest of shoot_ray's body ----------------------------------------------------
@@ -534,6 +630,7 @@ __global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
             P[r].ox = b.point.x; P[r].oy = b.point.y; P[r].oz = b.point.z;
             P[r].dx = b.dir.x; P[r].dy = b.dir.y; P[r].dz = b.dir.z;
             P[r].a = dot(b.dir, b.dir);
+            prep_segment(P[r]);
             P[r].depth--;
             ended = P[r].depth == 0;   // `if depth <= 0 { return black }`, src/main.rs:192-194
           }
@@ -582,7 +679,8 @@ template <bool STRICT>
 __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   extern __shared__ float4 lds[];
   float4* sph = lds;
-  uint16_t* qall = reinterpret_cast<uint16_t*>(lds + kChunkSpheres);
+  float* sr2 = reinterpret_cast<float*>(lds + kChunkSpheres);
+  uint16_t* qall = reinterpret_cast<uint16_t*>(sr2 + kChunkSpheres);
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = threadIdx.x / kWave;
   uint16_t* q = qall + wave * (R * Q * kWave);
@@ -597,6 +695,7 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     P[r].ox = P[r].oy = P[r].oz = 0.0f;
     P[r].dx = P[r].dy = P[r].dz = 0.0f;
     P[r].a = 1.0f;
+    prep_segment(P[r]);
     P[r].closest = kTMax;
     P[r].best = kNone;
   }
@@ -605,16 +704,17 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     P[0].ox = in.ox; P[0].oy = in.oy; P[0].oz = in.oz;
     P[0].dx = in.dx; P[0].dy = in.dy; P[0].dz = in.dz;
     P[0].a = dot(mk(in.dx, in.dy, in.dz), mk(in.dx, in.dy, in.dz));
+    prep_segment(P[0]);
     P[0].alive = true;
   }
   const uint32_t n = p.scene.n_spheres;
   for (uint32_t base = 0; base < n; base += kChunkSpheres) {
     const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < cn; k += kThreads) sph[k] = p.scene.geom[base + k];
+    stage_chunk(p.scene, base, cn, sph, sr2);
     __syncthreads();
     PhaseClock clk = {0, 0, 0, 0, 0, 0};
-    scan_chunk<STRICT>(P, sph, cn, base, q, lane, clk);
+    scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
   }
   if (!live) return;
 
@@ -656,8 +756,7 @@ constexpr size_t kQueueBytes = (size_t)kWavesPerWg * R * Q * kWave * sizeof(uint
 }  // namespace
 
 size_t trace_lds_bytes(uint32_t n_spheres) {
-  const size_t cap = n_spheres > kChunkSpheres ? kChunkSpheres : n_spheres;
-  return cap * sizeof(float4) + kQueueBytes;
+  return (size_t)lds_capacity(n_spheres) * (sizeof(float4) + sizeof(float)) + kQueueBytes;
 }
 
 template <bool STRICT, bool MULTI>
@@ -695,7 +794,7 @@ hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream) {
 
 hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream) {
   if (p.n_rays == 0) return hipSuccess;
-  const size_t lds = kChunkSpheres * sizeof(float4) + kQueueBytes;
+  const size_t lds = (size_t)kChunkSpheres * (sizeof(float4) + sizeof(float)) + kQueueBytes;
   const dim3 grid((p.n_rays + kThreads - 1) / kThreads), block(kThreads);
   if (strict) hipLaunchKernelGGL((hook_kernel<true>), grid, block, lds, stream, p);
   else hipLaunchKernelGGL((hook_kernel<false>), grid, block, lds, stream, p);

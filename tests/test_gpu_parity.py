@@ -1,13 +1,15 @@
 """GPU parity tests: the HIP path (through the C ABI of librt_hip.so) against the CPU oracle.
 
 Bars
- * STRICT_FP mode: every per-ray field and every per-pixel sum is BIT-IDENTICAL to the oracle
-   (the oracle's loop form with pow5 by multiplication, which is the arithmetic the kernel
-   states; the oracle's recursive/powf form is tied to it in test_oracle_known_answers.py).
- * default (fused multiply-add in the discriminant scan): hit distance, normal and scatter
-   direction within 1e-5 relative on identical rays; images within Monte-Carlo noise of the
-   oracle (PSNR >= 40 dB, channel means within 0.5 %) - in practice all but a handful of
-   pixels are bit-identical because only tangent-ray decisions can differ.
+ * Every per-ray field (hit distance, point, normal, scatter direction, draws) and every
+   per-pixel sum is BIT-IDENTICAL to the oracle, in the default mode and in STRICT_FP mode
+   alike.  "The oracle" is its loop form with pow5 by multiplication, which is the arithmetic
+   the kernel states; the oracle's recursive/powf form (the reference's own text) is tied to it
+   in test_oracle_known_answers.py.  This is far inside the stated tolerances (1e-5 relative
+   per ray; PSNR >= 40 dB and channel means within 0.5 % per image), which the tests also
+   assert explicitly against the recursive/powf oracle.
+ * The default mode's discriminant scan is a conservative filter in front of the exact
+   arithmetic, so it may only ever add work, never change a result: default == STRICT.
 """
 import ctypes as C
 
@@ -77,16 +79,21 @@ def test_per_ray_strict_is_bit_identical(grid):
     assert set(np.unique(ref["front_face"][ref["hit"] == 1])) == {0, 1}
 
 
-def test_per_ray_default_mode_within_1e5_relative():
+def test_per_ray_default_mode_is_bit_identical_and_within_1e5_of_the_powf_oracle():
     s, m = O.random_world(1, -11, 11)
     cam = default_camera()
     rays = make_rays((s, m), cam, 3000, seed=5)
-    ref = O.bounce(O.make_world(s, m), rays, seed=9, pow5_mode=O.RO_POW5_MUL)
     scene = hip.Scene(s, m)
     got = hip.trace_rays(scene, rays, seed=9, flags=0)
+    exact = O.bounce(O.make_world(s, m), rays, seed=9, pow5_mode=O.RO_POW5_MUL)
+    for f in INT_FIELDS:
+        assert np.array_equal(got[f], exact[f]), f
+    for f in FLOAT_FIELDS:
+        assert np.array_equal(got[f].view(np.uint32), exact[f].view(np.uint32)), f
+    # against the reference's own powf form: the stated 1e-5 relative tolerance
+    ref = O.bounce(O.make_world(s, m), rays, seed=9, pow5_mode=O.RO_POW5_LIBM)
     same = (got["hit"] == ref["hit"]) & (got["sphere"] == ref["sphere"])
-    # only a ray within rounding of tangency may pick a different sphere
-    assert np.count_nonzero(~same) <= 2
+    assert np.count_nonzero(~same) == 0
     h = same & (ref["hit"] == 1)
     t_rel = np.abs(got["t"][h] - ref["t"][h]) / np.abs(ref["t"][h])
     assert t_rel.max() <= 1e-5          # tolerance of the per-ray parity requirement
@@ -95,7 +102,8 @@ def test_per_ray_default_mode_within_1e5_relative():
         b = np.stack([ref[f][h] for f in group], axis=1).astype(np.float64)
         err = np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)
         assert err.max() <= 1e-5
-    assert np.array_equal(got["draws"][h], ref["draws"][h])
+    # a reflect/refract choice may flip only where reflectance is within 2 ulp of the draw
+    assert np.count_nonzero(got["draws"][h] != ref["draws"][h]) == 0
 
 
 def test_per_ray_equal_t_later_sphere_wins_and_empty_world():
@@ -141,13 +149,14 @@ def test_default_mode_image_matches_oracle():
     tiles = O.job_queue(w, h, 64, 64)
     ref_fb, ref, ctr = oracle_sums(s, m, cam, w, h, spp, 50, 5, tiles)
     got = hip.render_tiles(s, m, cam, w, h, spp, 50, 5, tiles, flags=SEQ)
-    npx = w * h
-    differing = np.count_nonzero(np.any(got.view(np.uint32) != ref.view(np.uint32), axis=1))
-    # only samples with a ray within rounding of tangency to some sphere may differ
-    assert differing <= npx // 200
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    strict = hip.render_tiles(s, m, cam, w, h, spp, 50, 5, tiles, flags=SEQ | STRICT)
+    assert np.array_equal(got.view(np.uint32), strict.view(np.uint32))
+    # against the reference's own recursive/powf form: the stated image tolerances
+    ref_fb, _, _ = oracle_sums(s, m, cam, w, h, spp, 50, 5, tiles, mode=O.RO_MODE_RECURSIVE)
     fb = hip.compose(tiles, got, w, h, spp)
     ok = ~(np.isnan(fb) | np.isnan(ref_fb))
-    assert np.array_equal(np.isnan(fb), np.isnan(ref_fb)) or differing > 0
+    assert np.count_nonzero(np.isnan(fb) != np.isnan(ref_fb)) <= 2
     mse = np.mean((fb[ok].astype(np.float64) - ref_fb[ok]) ** 2)
     psnr = 10 * np.log10(1.0 / max(mse, 1e-30))
     assert psnr >= 40.0

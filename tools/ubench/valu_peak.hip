@@ -96,6 +96,54 @@ __global__ void k_disc(const float4* __restrict__ spheres, int n, int reps, floa
   out[tid] = (float)tot;
 }
 
+// ---- 3. two spheres per packed instruction.  LDS holds sphere PAIRS:
+//   pairs[2k]   = (cx0, cx1, cy0, cy1),  pairs[2k+1] = (cz0, cz1, r2_0, r2_1)
+// Ray components are scalars splat into both halves (free: op_sel).  NORM drops the a*c
+// multiply (direction pre-normalised): 10 packed instructions per 2 tests, else 11.
+template <int R, bool NORM>
+__global__ void k_disc_pk(const float4* __restrict__ pairs, int npairs, int reps, float* out) {
+  extern __shared__ float4 lds[];
+  for (int i = threadIdx.x; i < 2 * npairs; i += blockDim.x) lds[i] = pairs[i];
+  __syncthreads();
+  float ox[R], oy[R], oz[R], dx[R], dy[R], dz[R], a[R];
+  int cnt[R];
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned h = (tid * R + r) * 2654435761u;
+    ox[r] = 13.f + (h & 255) * 1e-3f; oy[r] = 2.f + ((h >> 8) & 255) * 1e-3f; oz[r] = 3.f;
+    dx[r] = -0.96f + ((h >> 16) & 255) * 1e-3f; dy[r] = -0.15f; dz[r] = -0.22f + (h >> 24) * 1e-3f;
+    a[r] = dx[r] * dx[r] + dy[r] * dy[r] + dz[r] * dz[r];
+    cnt[r] = 0;
+  }
+  for (int rep = 0; rep < reps; ++rep) {
+#pragma unroll 2
+    for (int k = 0; k < npairs; ++k) {
+      const float4 A = lds[2 * k], B = lds[2 * k + 1];
+      const f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const f2 ocx = f2(ox[r]) - cx, ocy = f2(oy[r]) - cy, ocz = f2(oz[r]) - cz;
+        const f2 hb = __builtin_elementwise_fma(ocz, f2(dz[r]),
+                      __builtin_elementwise_fma(ocy, f2(dy[r]), ocx * f2(dx[r])));
+        const f2 cc = __builtin_elementwise_fma(ocz, ocz,
+                      __builtin_elementwise_fma(ocy, ocy, __builtin_elementwise_fma(ocx, ocx, -r2)));
+        f2 disc;
+        if (NORM) disc = __builtin_elementwise_fma(hb, hb, -cc);
+        else disc = __builtin_elementwise_fma(hb, hb, -(f2(a[r]) * cc));
+        if (!(disc.x < 0.f)) cnt[r]++;
+        if (!(disc.y < 0.f)) cnt[r]++;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) ox[r] += 1e-6f;
+  }
+  int tot = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) tot += cnt[r];
+  out[tid] = (float)tot;
+}
+
 static float time_ms(hipEvent_t e0, hipEvent_t e1) { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
 
 int main(int argc, char** argv) {
@@ -144,7 +192,35 @@ int main(int argc, char** argv) {
     printf("%-10s R=%d waves/SIMD %d : %8.3f ms  %7.2f Gtests/s  %6.2f TFLOP/s (17/test) = %5.1f%% of 157.3\n",
            name, R, wps, ms, tests / ms * 1e-6, tests * 17 / ms * 1e-9, tests * 17 / ms * 1e-9 / 157.3 * 100);
   };
-  for (int wps : {2, 4, 8}) {
+  {
+    std::vector<float4> hp(n);   // n/2 pairs, two float4 each
+    for (int k = 0; k < n / 2; ++k) {
+      hp[2 * k] = make_float4(hs[2 * k].x, hs[2 * k + 1].x, hs[2 * k].y, hs[2 * k + 1].y);
+      hp[2 * k + 1] = make_float4(hs[2 * k].z, hs[2 * k + 1].z, hs[2 * k].w, hs[2 * k + 1].w);
+    }
+    float4* dp; CK(hipMalloc(&dp, sizeof(float4) * n));
+    CK(hipMemcpy(dp, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    auto runp = [&](const char* name, auto kern, int R, int wps) {
+      int threads = 256, blocks = cus * wps;
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), n * sizeof(float4), 0, dp, n / 2, reps, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      }
+      CK(hipGetLastError());
+      double tests = (double)blocks * threads * R * n * reps;
+      float ms = time_ms(e0, e1);
+      printf("%-10s R=%d waves/SIMD %d : %8.3f ms  %7.2f Gtests/s  %6.2f TFLOP/s (17/test) = %5.1f%% of 157.3\n",
+             name, R, wps, ms, tests / ms * 1e-6, tests * 17 / ms * 1e-9, tests * 17 / ms * 1e-9 / 157.3 * 100);
+    };
+    for (int wps : {2, 4, 8}) {
+      runp("pk2", k_disc_pk<1, false>, 1, wps);
+      runp("pk2", k_disc_pk<2, false>, 2, wps);
+      runp("pk2norm", k_disc_pk<1, true>, 1, wps);
+      runp("pk2norm", k_disc_pk<2, true>, 2, wps);
+    }
+  }
+  for (int wps : {4}) {
     run("lds", k_disc<1, false>, 1, wps);
     run("lds", k_disc<2, false>, 2, wps);
     run("lds", k_disc<4, false>, 4, wps);
