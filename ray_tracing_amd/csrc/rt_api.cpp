@@ -107,26 +107,58 @@ int check_frame(const rt_frame* f) {
   return RT_OK;
 }
 
-// Work items per pixel.  One pixel's samples are cut into `slices` contiguous runs, each an
-// independent work item whose sum lands in its own plane of a partial buffer; a second kernel
-// adds the planes in slice order.  Two reasons to cut:
+// How one pixel's samples are cut into work items.  Slice k runs samples
+// [begin[k], begin[k+1]); its sum lands in plane k of a partial buffer and a second kernel adds
+// the planes in slice order.  Two reasons to cut:
 //  * granularity: a path at max_depth 50 inside glass can cost 20x the average, and a lane
-//    runs its item to the end while the frame's last items drain, so an item must be a small
-//    fraction of the frame (about kSamplesPerItem samples);
+//    runs its item to the end while the frame's last items drain, so items must be small where
+//    it matters.  The last eight slices are tapered down to single samples
+//    (.., B, B, 4, 4, 2, 2, 1, 1, 1, 1) and issued after all the full-size ones, so what
+//    drains last is small.
 //  * small images: fewer pixels than lanes.
-// The count is a function of the FULL image and spp only, so a frame gives the same sums
+// The cut is a function of the FULL image and spp only, so a frame gives the same sums
 // whatever part of it a call renders and however many GPUs share it.
-uint32_t choose_slices(const rt_frame& f) {
-  if (f.flags & RT_FLAG_SEQUENTIAL_SUM) return 1;
-  const uint64_t pixels = (uint64_t)f.image_width * f.image_height;
-  const uint64_t spp = f.samples_per_pixel;
-  uint64_t by_grain = (spp + rt::kSamplesPerItem - 1) / rt::kSamplesPerItem;
-  if (by_grain > rt::kMaxGrainSlices) by_grain = rt::kMaxGrainSlices;
-  uint64_t by_fill = pixels >= rt::kTargetItems ? 1 : (rt::kTargetItems + pixels - 1) / pixels;
-  uint64_t s = by_grain > by_fill ? by_grain : by_fill;
-  if (s > spp) s = spp;
-  if (s > 64) s = 64;
-  return (uint32_t)s;
+std::vector<uint32_t> plan_slices(const rt_frame& f, uint32_t* body_slices) {
+  const uint32_t spp = f.samples_per_pixel;
+  std::vector<uint32_t> sizes;
+  uint32_t tail = 0;
+  if (f.flags & RT_FLAG_SEQUENTIAL_SUM) {
+    sizes.push_back(spp);
+  } else {
+    static const uint32_t taper[8] = {4, 4, 2, 2, 1, 1, 1, 1};   // 16 samples
+    if (spp >= 32) {
+      const uint32_t body = spp - 16;
+      uint32_t big = rt::kSamplesPerItem;
+      const uint32_t room = rt::kMaxSlices - 8 - 1;
+      if ((body + big - 1) / big > room) big = (body + room - 1) / room;
+      for (uint32_t left = body; left > 0;) {
+        const uint32_t n = left < big ? left : big;
+        sizes.push_back(n);
+        left -= n;
+      }
+      for (uint32_t t : taper) sizes.push_back(t);
+      tail = 8;
+    } else {
+      const uint32_t count = (spp + rt::kSamplesPerItem - 1) / rt::kSamplesPerItem;
+      for (uint32_t k = 0; k < count; ++k)
+        sizes.push_back((uint32_t)(((uint64_t)(k + 1) * spp) / count - ((uint64_t)k * spp) / count));
+    }
+    // small image: more, equal slices so that every lane has an item
+    const uint64_t pixels = (uint64_t)f.image_width * f.image_height;
+    uint64_t want = pixels >= rt::kTargetItems ? 1 : (rt::kTargetItems + pixels - 1) / pixels;
+    if (want > spp) want = spp;
+    if (want > rt::kMaxSlices) want = rt::kMaxSlices;
+    if (want > sizes.size()) {
+      sizes.clear();
+      tail = 0;
+      for (uint64_t k = 0; k < want; ++k)
+        sizes.push_back((uint32_t)(((k + 1) * spp) / want - (k * spp) / want));
+    }
+  }
+  std::vector<uint32_t> begin(1, 0);
+  for (uint32_t n : sizes) begin.push_back(begin.back() + n);
+  *body_slices = (uint32_t)sizes.size() - tail;
+  return begin;
 }
 
 int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
@@ -151,7 +183,9 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   p.spp = frame->samples_per_pixel;
   p.seed_a = rt_rng_seed_a(frame->seed);
   p.seed_b = rt_rng_seed_b(frame->seed);
-  p.slices = choose_slices(*frame);
+  const std::vector<uint32_t> slice_begin = plan_slices(*frame, &p.body_slices);
+  p.slices = (uint32_t)slice_begin.size() - 1;
+  for (size_t k = 0; k < slice_begin.size(); ++k) p.slice_begin[k] = slice_begin[k];
   p.n_tiles = (uint32_t)tiles.size();
   uint64_t total_pixels = 0;
   for (const rt::TileDev& t : tiles) total_pixels += (uint64_t)t.w * t.h;
@@ -211,8 +245,6 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
       RT_HIP(hipMalloc((void**)&g.partial, need * sizeof(float)));
       g.partial_cap = need;
     }
-    // tiles need not cover the output: pixels no tile writes must read as 0 in every slice
-    RT_HIP(hipMemsetAsync(g.partial, 0, need * sizeof(float), stream));
     trace_out = g.partial;
     p.resolve = 0;
   } else {
@@ -244,6 +276,10 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
     rp.out = d_out;
     rp.out_pixels = out_pixels;
     rp.slices = p.slices;
+    rp.n_tiles = p.n_tiles;
+    rp.total_pixels = p.total_pixels;
+    rp.tile0 = p.tile0;
+    rp.tiles = p.tiles;
     rp.resolve = resolve;
     rp.inv_spp = p.inv_spp;
     RT_HIP(rt::launch_reduce(rp, stream));

@@ -18,8 +18,8 @@ constexpr uint32_t kChunkSpheres = 2048; // sphere records resident in LDS at a 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic
 constexpr uint32_t kTargetItems = 1u << 20; // below this many pixels, split samples over lanes
-constexpr uint32_t kSamplesPerItem = 8;     // samples one work item runs (tail granularity)
-constexpr uint32_t kMaxGrainSlices = 16;    // cap on slices chosen for granularity alone
+constexpr uint32_t kSamplesPerItem = 8;     // samples one full-size work item runs
+constexpr uint32_t kMaxSlices = 64;         // planes of the partial-sum buffer, at most
 
 // One tile of the request as the kernel sees it.
 struct TileDev {
@@ -61,7 +61,10 @@ struct TraceParams {
   uint32_t width, height;
   uint32_t max_depth, spp;
   uint32_t seed_a, seed_b;  // rt_rng_seed_a/b(seed)
-  uint32_t slices;          // lanes sharing one pixel's samples
+  uint32_t slices;          // work items (and partial-sum planes) per pixel
+  uint32_t body_slices;     // the first body_slices slices are issued first, pixel-major;
+                            // the remaining (short) ones after them, pixel-major again
+  uint32_t slice_begin[kMaxSlices + 1];   // slice k runs samples [slice_begin[k], slice_begin[k+1])
   uint32_t n_tiles;
   uint32_t total_pixels;
   uint32_t total_items;     // total_pixels * slices
@@ -79,6 +82,10 @@ struct ReduceParams {
   float* out;             // [out_pixels][3]
   uint64_t out_pixels;
   uint32_t slices;
+  uint32_t n_tiles;
+  uint32_t total_pixels;  // pixels the tiles cover; only these are summed and written
+  TileDev tile0;
+  const TileDev* tiles;
   int resolve;
   float inv_spp;
 };

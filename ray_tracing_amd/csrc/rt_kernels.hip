@@ -445,21 +445,37 @@ __device__ __forceinline__ uint32_t wave_fetch(bool need, uint32_t& next, uint32
   return item;
 }
 
+// Pixel g of the call's tile list -> its tile (tiles are ordered by first_pixel).
+__device__ __forceinline__ TileDev find_tile(uint32_t g, uint32_t n_tiles, const TileDev& tile0,
+                                             const TileDev* tiles) {
+  if (n_tiles == 1) return tile0;
+  uint32_t lo = 0, hi = n_tiles;   // largest k with tiles[k].first_pixel <= g
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (tiles[mid].first_pixel <= g) lo = mid; else hi = mid;
+  }
+  return tiles[lo];
+}
+
+// Item numbering: first every pixel's body slices, pixel-major (the lanes of a wave then sit
+// on the same few pixels, so their paths meet the same spheres and fewer scan blocks branch
+// to the candidate code); then every pixel's short tail slices, pixel-major again, so that
+// the items that drain last are small.
 __device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TraceParams& p) {
   uint32_t g = item, sl = 0;
   if (p.slices != 1) {
-    g = item / p.slices;
-    sl = item - g * p.slices;
-  }
-  TileDev t = p.tile0;
-  if (p.n_tiles != 1) {
-    uint32_t lo = 0, hi = p.n_tiles;   // largest k with tiles[k].first_pixel <= g
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (p.tiles[mid].first_pixel <= g) lo = mid; else hi = mid;
+    const uint32_t body_items = p.total_pixels * p.body_slices;
+    if (item < body_items) {
+      g = item / p.body_slices;
+      sl = item - g * p.body_slices;
+    } else {
+      const uint32_t tail_slices = p.slices - p.body_slices;
+      const uint32_t j = item - body_items;
+      g = j / tail_slices;
+      sl = p.body_slices + (j - g * tail_slices);
     }
-    t = p.tiles[lo];
   }
+  const TileDev t = find_tile(g, p.n_tiles, p.tile0, p.tiles);
   const uint32_t local = g - t.first_pixel;
   const uint32_t ty = local / t.w;
   const uint32_t tx = local - ty * t.w;
@@ -468,8 +484,8 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TracePa
   P.fy = (float)py;
   P.pixel = py * p.width + px;
   P.out_index = (uint32_t)(t.out_offset + (uint64_t)ty * t.out_stride + tx + sl * p.out_pixels);
-  P.sample = (uint32_t)(((unsigned long long)sl * p.spp) / p.slices);
-  P.sample_end = (uint32_t)(((unsigned long long)(sl + 1) * p.spp) / p.slices);
+  P.sample = p.slice_begin[sl];
+  P.sample_end = p.slice_begin[sl + 1];
   P.ar = P.ag = P.ab = 0.0f;
   P.has_item = true;
 }
@@ -662,14 +678,29 @@ __global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
   }
 }
 
-// Sum the slices of each pixel in slice order and optionally resolve.
+// Sum the planes of each covered pixel in slice order and optionally resolve
+// (compose_final_framebuffer's arithmetic, src/cpu/mod.rs:67-75).
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
-  const uint64_t n = p.out_pixels * 3ull;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (uint64_t)gridDim.x * blockDim.x) {
-    float s = p.partial[i];
-    for (uint32_t k = 1; k < p.slices; ++k) s += p.partial[(uint64_t)k * n + i];
-    p.out[i] = p.resolve ? resolve_channel(s, p.inv_spp) : s;
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < p.total_pixels;
+       g += gridDim.x * blockDim.x) {
+    const TileDev t = find_tile(g, p.n_tiles, p.tile0, p.tiles);
+    const uint32_t local = g - t.first_pixel;
+    const uint32_t ty = local / t.w;
+    const uint32_t tx = local - ty * t.w;
+    const uint64_t o = t.out_offset + (uint64_t)ty * t.out_stride + tx;
+    const float* src = p.partial + 3ull * o;
+    float r = src[0], gch = src[1], b = src[2];
+    for (uint32_t k = 1; k < p.slices; ++k) {
+      const float* pl = src + 3ull * k * p.out_pixels;
+      r += pl[0]; gch += pl[1]; b += pl[2];
+    }
+    if (p.resolve) {
+      r = resolve_channel(r, p.inv_spp);
+      gch = resolve_channel(gch, p.inv_spp);
+      b = resolve_channel(b, p.inv_spp);
+    }
+    float* dst = p.out + 3ull * o;
+    dst[0] = r; dst[1] = gch; dst[2] = b;
   }
 }
 
@@ -784,9 +815,8 @@ hipError_t launch_trace(const TraceParams& p, bool strict, int blocks, hipStream
 }
 
 hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream) {
-  const uint64_t n = p.out_pixels * 3ull;
-  uint64_t blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  uint64_t blocks = ((uint64_t)p.total_pixels + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
   if (blocks == 0) return hipSuccess;
   hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
   return hipGetLastError();

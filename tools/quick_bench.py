@@ -1,7 +1,6 @@
 """Developer benchmark: time the path-tracing kernel on one configuration and print the
-roofline fraction.  Usage: python tools/quick_bench.py [grid_hi] [width] [height] [spp] [flags]
-The scene comes from the product's host mirror when available, else from the test oracle
-(this is a developer tool, not the product path)."""
+roofline fraction.
+Usage: python tools/quick_bench.py [grid_hi] [width] [height] [spp] [flags] [reps] [glass]"""
 import os
 import sys
 
@@ -9,12 +8,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch  # noqa: E402
 
-import oracle_lib as O  # noqa: E402
-from ray_tracing_amd import hip  # noqa: E402
+from ray_tracing_amd import hip, host  # noqa: E402
 
 PEAK_TFLOPS = 157.3
 
@@ -26,11 +23,14 @@ def main():
     spp = int(sys.argv[4]) if len(sys.argv) > 4 else 100
     flags = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     reps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
+    glass = len(sys.argv) > 7 and sys.argv[7] == "glass"
     hip.init(0)
-    s, m = O.random_world(1, -hi, hi)
-    cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, w / h)
-    scene = hip.Scene(s, m)
-    frame = hip.make_frame(cam, w, h, spp, 50, 1, flags)
+    world = (host.create_random_world(1, (-hi, hi), 0.1, 0.2, True) if glass
+             else host.create_random_world(1, (-hi, hi)))
+    s = world.spheres
+    cam = host.Camera.new((13, 2, 3), (0, 0, 0), 20.0, w / h)
+    scene = hip.Scene(world.spheres, world.materials)
+    frame = hip.make_frame(cam.m, w, h, spp, 50, 1, flags)
     out = torch.empty((h, w, 3), dtype=torch.float32, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     for rep in range(reps):
