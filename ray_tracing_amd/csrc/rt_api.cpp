@@ -72,6 +72,8 @@ State g;
 //
 // The scan decides which spheres get the reference's exact Sphere::hit arithmetic.  It evaluates
 //     disc' = hb'^2 - c',   hb' = o.dn - c.dn,   c' = k' - 2 o.c + |o|^2 (1 - 2^-17)
+// (the record stores -k'/2 so that the kernel can use o itself instead of -2 o; the halving and
+// doubling are exact)
 // with dn = d/|d| (slightly lengthened), i.e. the reference's discriminant divided by |d|^2 and
 // expanded so that no o - c subtraction is needed (8 instead of 11 vector instructions).  The
 // expansion rounds differently from src/main.rs:131-135, so k' carries a slack that makes the
@@ -87,7 +89,7 @@ float trigger_constant(const rt_sphere& s) {
   const double k = c2 - r2 - std::ldexp(c2, -17) - std::ldexp(r2, -19);
   float kf = (float)k;
   if ((double)kf > k) kf = std::nextafterf(kf, -INFINITY);
-  return kf;
+  return -0.5f * kf;
 }
 
 int check_ready() {

@@ -12,9 +12,10 @@ constexpr int kWave = 64;
 constexpr int kThreads = 512;           // 8 waves per workgroup
 constexpr int kWavesPerWg = kThreads / kWave;
 constexpr int kRaysPerLane = 2;         // independent paths blocked into one lane
-constexpr int kQueueSlots = 16;         // deferred-candidate slots per path (u16 each)
+constexpr int kQueueSlots = 20;         // deferred-candidate slots per path (u16 each)
 constexpr int kScanUnroll = 4;          // spheres per unrolled block of the scan
-constexpr uint32_t kChunkSpheres = 2048; // sphere records resident in LDS at a time (32 KiB)
+constexpr uint32_t kChunkSpheres = 2016; // spheres resident in LDS at a time: with the read-ahead
+                                         // padding and the queues, two workgroups fill a CU's LDS
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic
 constexpr uint32_t kTargetItems = 1u << 20; // below this many pixels, split samples over lanes
@@ -30,7 +31,7 @@ struct TileDev {
 };
 
 // Device copy of a World (reference src/main.rs:168-172), split hot/cold:
-//   trig[i] = (cx, cy, cz, k')                  read by every ray for every sphere; k' is
+//   trig[i] = (cx, cy, cz, -k'/2)               read by every ray for every sphere; k' is
 //             |c|^2 - r^2 minus a rounding slack (see trigger_constant in rt_api.cpp)
 //   geom[i] = (cx, cy, cz, radius*radius)       read when a sphere is replayed exactly
 //   aux[i]  = (radius, material_id bits)        read once per hit

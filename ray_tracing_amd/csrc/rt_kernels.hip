@@ -20,7 +20,7 @@
 //    discriminant half_b^2 - a*c of src/main.rs:131-135 (17 flops as written there).  It does so
 //    on an expanded, pre-normalised form, hb' = o.dn - c.dn and c' = k' - 2 o.c + |o|^2, which
 //    needs no o - c subtraction: 8 fused VALU instructions per ray/sphere pair.  The sphere
-//    record (cx,cy,cz,k') is one wave-uniform 16-byte LDS read shared by both paths of every
+//    record (cx,cy,cz,-k'/2) is one wave-uniform 16-byte LDS read shared by both paths of every
 //    lane.  k' and |o|^2 carry a slack that bounds the rounding of both forms, so the scan never
 //    skips a sphere the reference's own arithmetic would accept (derivation: trigger_constant in
 //    rt_api.cpp).  A sphere that passes is appended to a small per-path queue in LDS.  After
@@ -60,9 +60,14 @@ struct PhaseClock {
   unsigned long long t0, refill, scan, replay, shade, steps;
 };
 
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 4   // 4 waves per SIMD = 2 workgroups per CU: at most 128 VGPRs
+#endif
+
 constexpr int R = kRaysPerLane;
 constexpr int Q = kQueueSlots;
 constexpr int U = kScanUnroll;
+static_assert(Q > 2 * U + (U - 1), "queue must hold two blocks plus the scan's tail");
 constexpr float kTMin = 0.001f;  // src/main.rs:196
 constexpr float kTMax = FLT_MAX; // f32::MAX, src/main.rs:196
 
@@ -167,6 +172,53 @@ __device__ __forceinline__ void exact_hit(float4 s, uint32_t index, V3 o, V3 d, 
   best = index;
 }
 
+// ---- the same decision for a candidate visited in ANY order ----------------------------------
+// World::hit's loop keeps the minimum, over spheres, of f = (first root if >= t_min, else second
+// root if >= t_min), a later sphere replacing an earlier one at equal f (the rejection is the
+// strict `t_max < root`).  That is independent of the visiting order once the tie rule is
+// explicit, so candidates can be visited last-to-first (the big spheres sit at the end of the
+// reference's scenes, so `closest` tightens early) and most of them can be turned away before
+// the correctly rounded sqrt and divisions by three tests that are safe in floating point:
+//  (i)   half_b > 0 and c > 0: sqrtd <= half_b, so the second root is <= 0 < t_min;
+//  (ii)  a lower bound of the first root's numerator already exceeds closest * a;
+//  (iii) an upper bound of the second root's numerator is already below t_min * a.
+// (ii) and (iii) use the 1-ulp hardware sqrt widened by 2^-20, and 2^-20 / 2^-19 margins on
+// both sides, far more than the few 2^-24 roundings involved.  Requires a finite, non-zero
+// ray (prep_segment's `degenerate` is false); the caller falls back to exact_hit otherwise.
+struct ReplayBounds {
+  float closest_a;   // >= closest * a   (infinite while nothing is hit)
+  float tmin_a;      // <= t_min * a
+};
+__device__ __forceinline__ ReplayBounds replay_bounds(float closest, float a) {
+  ReplayBounds b;
+  b.closest_a = (closest * a) * 1.00000095367431640625f;   // 1 + 2^-20
+  b.tmin_a = (kTMin * a) * 0.99999809265136718750f;        // 1 - 2^-19
+  return b;
+}
+__device__ __forceinline__ void candidate_hit(float4 s, uint32_t index, V3 o, V3 d, float a,
+                                              ReplayBounds& rb, float& closest, uint32_t& best) {
+  V3 oc = sub(o, mk(s.x, s.y, s.z));
+  float half_b = dot(oc, d);
+  float c = dot(oc, oc) - s.w;   // s.w = radius * radius
+  float discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0f) return;
+  if (half_b > 0.0f && c > 0.0f) return;                                            // (i)
+  const float s_hi = __builtin_amdgcn_sqrtf(discriminant) * 1.00000095367431640625f;
+  if ((-half_b - s_hi) * 0.99999904632568359375f > rb.closest_a) return;            // (ii)
+  if ((-half_b + s_hi) * 1.00000190734863281250f < rb.tmin_a) return;               // (iii)
+  float sqrtd = __builtin_sqrtf(discriminant);
+  float root = (-half_b - sqrtd) / a;
+  if (root < kTMin) {
+    root = (-half_b + sqrtd) / a;
+    if (root < kTMin) return;
+  }
+  if (root < closest || (root == closest && (best == kNone || index > best))) {
+    closest = root;
+    best = index;
+    rb = replay_bounds(closest, a);
+  }
+}
+
 // ---- one segment's scatter decision, the body of shoot_ray, src/main.rs:196-251 -------------
 struct Bounce {
   uint32_t kind;
@@ -227,11 +279,12 @@ __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, floa
   return b;
 }
 
-// Sphere records the LDS buffer holds: the whole scene, or one chunk.  Rounded up to a
-// multiple of 4 so that the radius^2 array behind the records stays 16-byte aligned.
-__host__ __device__ __forceinline__ uint32_t lds_capacity(uint32_t n_spheres) {
+// Sphere records the LDS buffer holds: the whole scene, or one chunk, plus 2*U records of
+// padding for the scan's read-ahead.  A multiple of 4, so that the radius^2 array behind the
+// records stays 16-byte aligned.
+__host__ __device__ constexpr uint32_t lds_capacity(uint32_t n_spheres) {
   const uint32_t cap = n_spheres > kChunkSpheres ? kChunkSpheres : n_spheres;
-  return (cap + 3u) & ~3u;
+  return ((cap + 3u) & ~3u) + 2u * kScanUnroll;
 }
 
 // Workgroup-cooperative copy of spheres [base, base+cn) into LDS.
@@ -252,8 +305,8 @@ struct Path {
   // constants of the conservative scan for this segment (prep_segment)
   float ndx, ndy, ndz;   // -d / |d|, lengthened by 2^-20
   float od;              // o . (d / |d|)
-  float o2x, o2y, o2z;   // -2 o
-  float oo;              // |o|^2 (1 - 2^-17)
+  float noo;             // -|o|^2 (1 - 2^-17)
+  bool degenerate;       // zero / non-finite ray: every sphere goes to the literal arithmetic
   float closest;
   uint32_t best;
   uint32_t cnt;     // queued candidates
@@ -278,22 +331,21 @@ __device__ __forceinline__ void prep_segment(Path& P) {
   const float dnx = P.dx * s, dny = P.dy * s, dnz = P.dz * s;
   P.ndx = -dnx; P.ndy = -dny; P.ndz = -dnz;
   P.od = __builtin_fmaf(P.oz, dnz, __builtin_fmaf(P.oy, dny, P.ox * dnx));
-  P.o2x = -2.0f * P.ox; P.o2y = -2.0f * P.oy; P.o2z = -2.0f * P.oz;
   const float oo = P.ox * P.ox + P.oy * P.oy + P.oz * P.oz;
-  P.oo = oo * 0.99999237060546875f;   // 1 - 2^-17
+  P.noo = -(oo * 0.99999237060546875f);   // 1 - 2^-17
   // A direction of zero, infinite or NaN length, or an origin that is not finite: the scan's
   // algebra does not apply, so make it pass every sphere on to the exact arithmetic (which
-  // then does whatever the reference does with such a ray).  hb' = +inf, c' = -inf.
+  // then does whatever the reference does with such a ray).  hb' = +inf, -c' = +inf.
   const float inf = __builtin_inff();
-  if (!(P.a > 0.0f) || !(P.a < inf) || !(oo < inf) || !(__builtin_fabsf(P.od) < inf)) {
+  P.degenerate = !(P.a > 0.0f) || !(P.a < inf) || !(oo < 1e37f) || !(__builtin_fabsf(P.od) < inf);
+  if (P.degenerate) {
     P.ndx = P.ndy = P.ndz = 0.0f;
-    P.o2x = P.o2y = P.o2z = 0.0f;
     P.od = inf;
-    P.oo = -inf;
+    P.noo = inf;
   }
 }
 
-// NB spheres against the R paths of the lane.  `s[u]` = (cx, cy, cz, k'), `r2[u]` = radius^2
+// NB spheres against the R paths of the lane.  `s[u]` = (cx, cy, cz, -k'/2), `r2[u]` = radius^2
 // (only read when STRICT).  All NB*R discriminants are evaluated first, as independent
 // instruction chains; their sign bits are folded with an integer max (a float with the sign
 // bit clear, NaN included, is a non-negative int) and ONE rarely-taken branch per block leads
@@ -316,9 +368,10 @@ __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&
       } else {        // conservative expanded form, 8 instructions
         const float hb = __builtin_fmaf(s[u].z, P[r].ndz,
                          __builtin_fmaf(s[u].y, P[r].ndy, __builtin_fmaf(s[u].x, P[r].ndx, P[r].od)));
-        const float cp = __builtin_fmaf(s[u].z, P[r].o2z,
-                         __builtin_fmaf(s[u].y, P[r].o2y, __builtin_fmaf(s[u].x, P[r].o2x, s[u].w)));
-        disc[u][r] = __builtin_fmaf(hb, hb, -(cp + P[r].oo));
+        // s.w = -k'/2, so qh = c.o - k'/2 and -c' = 2 qh - |o|^2(1 - 2^-17)
+        const float qh = __builtin_fmaf(s[u].z, P[r].oz,
+                         __builtin_fmaf(s[u].y, P[r].oy, __builtin_fmaf(s[u].x, P[r].ox, s[u].w)));
+        disc[u][r] = __builtin_fmaf(hb, hb, __builtin_fmaf(qh, 2.0f, P[r].noo));
       }
     }
   }
@@ -356,11 +409,12 @@ __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&
         }
       }
     }
-    // A block of U spheres adds at most U entries per path: ask for a replay while every
-    // queue still has room for the next block.
+    // The scan loop looks at `flush` once per TWO blocks, and two blocks add at most 2*U
+    // entries per path.  Asking for a replay as soon as a queue holds Q - 2*U entries keeps
+    // every queue within its Q slots: a path enters a loop iteration with fewer than Q - 2*U.
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (__builtin_amdgcn_ballot_w64(P[r].cnt >= (uint32_t)(Q - U)) != 0) flush = true;
+      if (__builtin_amdgcn_ballot_w64(P[r].cnt >= (uint32_t)(Q - 2 * U)) != 0) flush = true;
   }
 }
 
@@ -370,12 +424,26 @@ __device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, co
   for (int r = 0; r < R; ++r) {
     const uint32_t n = P[r].cnt;
     const V3 o = mk(P[r].ox, P[r].oy, P[r].oz), d = mk(P[r].dx, P[r].dy, P[r].dz);
-    for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0; ++k) {
-      if (k < n) {
-        const uint32_t li = q[(r * Q + k) * kWave + lane];
-        float4 rec = sph[li];
-        rec.w = sr2[li];
-        exact_hit(rec, chunk_base + li, o, d, P[r].a, P[r].closest, P[r].best);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(P[r].degenerate && n != 0) != 0, 0)) {
+      // some lane carries a zero or non-finite ray: the whole wave takes the literal loop,
+      // first to last, which is the reference for every ray
+      for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0; ++k) {
+        if (k < n) {
+          const uint32_t li = q[(r * Q + k) * kWave + lane];
+          float4 rec = sph[li];
+          rec.w = sr2[li];
+          exact_hit(rec, chunk_base + li, o, d, P[r].a, P[r].closest, P[r].best);
+        }
+      }
+    } else {
+      ReplayBounds rb = replay_bounds(P[r].closest, P[r].a);
+      for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0; ++k) {
+        if (k < n) {
+          const uint32_t li = q[(r * Q + (n - 1 - k)) * kWave + lane];   // last to first
+          float4 rec = sph[li];
+          rec.w = sr2[li];
+          candidate_hit(rec, chunk_base + li, o, d, P[r].a, rb, P[r].closest, P[r].best);
+        }
       }
     }
     P[r].cnt = 0;
@@ -390,15 +458,36 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
   uint32_t i = 0;
   while (i < cn) {
     bool flush = false;
-    for (; i + U <= cn && !flush; i += U) {
-      float4 s[U];
-      float r2[U];
+    // The records of the next block are read from LDS while the current one is evaluated,
+    // so the read latency is off the critical path: two register sets, A and B, alternate
+    // (the loop body is two blocks long so that no set is ever copied).  The buffer is padded
+    // by 2*U records, so the read-ahead stays inside it; what it reads there is never used.
+    float4 A[U], B[U];
+    float rA[U], rB[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      A[u] = sph[i + u];
+      rA[u] = STRICT ? sr2[i + u] : 0.0f;
+    }
+    for (; i + 2 * U <= cn && !flush; i += 2 * U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        s[u] = sph[i + u];
-        r2[u] = STRICT ? sr2[i + u] : 0.0f;
+        B[u] = sph[i + U + u];
+        rB[u] = STRICT ? sr2[i + U + u] : 0.0f;
       }
-      test_block<STRICT, U>(s, r2, i, P, q, lane, flush);
+      __builtin_amdgcn_sched_barrier(0);   // keep the read-ahead ahead of the arithmetic
+      test_block<STRICT, U>(A, rA, i, P, q, lane, flush);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        A[u] = sph[i + 2 * U + u];
+        rA[u] = STRICT ? sr2[i + 2 * U + u] : 0.0f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      test_block<STRICT, U>(B, rB, i + U, P, q, lane, flush);
+    }
+    if (!flush && i + U <= cn) {
+      test_block<STRICT, U>(A, rA, i, P, q, lane, flush);
+      i += U;
     }
     if (!flush) {
       for (; i < cn; ++i) {
@@ -538,11 +627,11 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 }
 
 template <bool STRICT, bool MULTI>
-__global__ __launch_bounds__(kThreads) void trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const TraceParams p) {
   extern __shared__ float4 lds[];
   const uint32_t n = p.scene.n_spheres;
   const uint32_t cap = lds_capacity(n);
-  float4* sph = lds;                                       // (cx, cy, cz, k') per sphere
+  float4* sph = lds;                                       // (cx, cy, cz, -k'/2) per sphere
   float* sr2 = reinterpret_cast<float*>(lds + cap);        // radius^2 per sphere
   uint16_t* qall = reinterpret_cast<uint16_t*>(sr2 + cap);
   const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -710,8 +799,9 @@ template <bool STRICT>
 __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   extern __shared__ float4 lds[];
   float4* sph = lds;
-  float* sr2 = reinterpret_cast<float*>(lds + kChunkSpheres);
-  uint16_t* qall = reinterpret_cast<uint16_t*>(sr2 + kChunkSpheres);
+  constexpr uint32_t cap = lds_capacity(kChunkSpheres);
+  float* sr2 = reinterpret_cast<float*>(lds + cap);
+  uint16_t* qall = reinterpret_cast<uint16_t*>(sr2 + cap);
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = threadIdx.x / kWave;
   uint16_t* q = qall + wave * (R * Q * kWave);
@@ -824,7 +914,7 @@ hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream) {
 
 hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream) {
   if (p.n_rays == 0) return hipSuccess;
-  const size_t lds = (size_t)kChunkSpheres * (sizeof(float4) + sizeof(float)) + kQueueBytes;
+  const size_t lds = (size_t)lds_capacity(kChunkSpheres) * (sizeof(float4) + sizeof(float)) + kQueueBytes;
   const dim3 grid((p.n_rays + kThreads - 1) / kThreads), block(kThreads);
   if (strict) hipLaunchKernelGGL((hook_kernel<true>), grid, block, lds, stream, p);
   else hipLaunchKernelGGL((hook_kernel<false>), grid, block, lds, stream, p);

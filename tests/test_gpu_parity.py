@@ -242,7 +242,7 @@ def test_depth_zero_and_depth_one():
 
 
 def test_large_scene_is_streamed_through_lds_in_chunks():
-    # 2504 spheres > one LDS chunk (2048): closest hit must carry across chunks
+    # 2504 spheres > one LDS chunk (about 2000): closest hit must carry across chunks
     s, m = O.random_world(1, -25, 25)
     assert len(s) == 2504
     cam = default_camera()
