@@ -248,6 +248,11 @@ __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, floa
   b.normal = b.front ? outward : neg(outward);
   b.scattered = true;
 
+  // Both the metal and the diffuse branch start by drawing random_in_unit_sphere_vec3(); one
+  // loop serves the lanes of either kind (same draws, same order, per path).
+  V3 ball = mk(0.0f, 0.0f, 0.0f);
+  if (!(flags & RT_MAT_DIELECTRIC)) ball = random_in_unit_sphere(rng);
+
   if (flags & RT_MAT_DIELECTRIC) {                                // src/main.rs:201-227
     b.kind = RT_KIND_DIELECTRIC;
     float ir = m1.y;
@@ -264,7 +269,7 @@ __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, floa
     b.kind = RT_KIND_METAL;
     V3 reflected = reflect(d, b.normal);
     float fuzz = 1.0f - m1.x;
-    b.dir = add(reflected, scale(random_in_unit_sphere(rng), fuzz));
+    b.dir = add(reflected, scale(ball, fuzz));
     if (dot(reflected, b.normal) > 0.0f) {
       b.atten = mul(color, color);   // albedo applied twice, src/main.rs:199,236-237,242
     } else {
@@ -273,7 +278,7 @@ __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, floa
     }
   } else {                                                        // src/main.rs:243-251
     b.kind = RT_KIND_DIFFUSE;
-    b.dir = add(b.normal, normalize(random_in_unit_sphere(rng)));
+    b.dir = add(b.normal, normalize(ball));
     b.atten = color;
   }
   return b;
