@@ -30,6 +30,9 @@
 //    busy in the slow part instead of one lane per triggering sphere.
 //  * Scenes larger than kChunkSpheres are streamed through the same LDS buffer chunk by chunk
 //    by the whole workgroup (MULTI = true), carrying closest-hit across chunks.
+//  * When a wave has no work left and at most kTailPaths paths are still alive it stops scanning
+//    and traces them one at a time with the spheres spread across its lanes (tail_hit), so the
+//    deep paths that remain when a frame drains do not hold the GPU for long.
 //  * STRICT = true makes the scan evaluate the discriminant literally, in the reference's
 //    operation order without fused multiply-adds (17 instructions).  Both modes give the same
 //    bits; STRICT exists to check the conservative scan against the literal one.
@@ -507,6 +510,46 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
   }
 }
 
+// World::hit for the last few paths of a wave, one path at a time with the SPHERES spread over
+// the 64 lanes: lane l runs the exact test on spheres l, l+64, ... (read straight from global
+// memory, coalesced), then the wave takes the minimum t, the larger index winning a tie like a
+// later sphere does in World::hit's loop.  A step costs n/64 exact tests per lane instead of n
+// discriminants for all 128 paths, so the deep paths that are still alive when a frame drains
+// (max_depth 50 inside glass) finish an order of magnitude sooner.
+__device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, uint32_t lane) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned long long m = __builtin_amdgcn_ballot_w64(P[r].alive);
+    while (m != 0) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1;
+      const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].ox), src));
+      const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].oy), src));
+      const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].oz), src));
+      const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].dx), src));
+      const float dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].dy), src));
+      const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].dz), src));
+      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].a), src));
+      float c = kTMax;
+      uint32_t b = kNone;
+      ReplayBounds rb = replay_bounds(c, a);
+      for (uint32_t i = lane; i < sc.n_spheres; i += kWave)
+        candidate_hit(sc.geom[i], i, mk(ox, oy, oz), mk(dx, dy, dz), a, rb, c, b);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(c, off, kWave);
+        const uint32_t ob = (uint32_t)__shfl_xor((int)b, off, kWave);
+        const bool take = ob != kNone && (b == kNone || oc < c || (oc == c && ob > b));
+        if (take) { c = oc; b = ob; }
+      }
+      if (lane == (uint32_t)src) {
+        P[r].closest = c;
+        P[r].best = b;
+      }
+    }
+  }
+}
+
 // Reserve work for the lanes of this wave whose `need` is set.  Returns the lane's item or
 // kNone once the frame's items are exhausted.  Must be called by all 64 lanes.
 __device__ __forceinline__ uint32_t wave_fetch(bool need, uint32_t& next, uint32_t& end,
@@ -706,16 +749,31 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
       P[r].best = kNone;
       P[r].cnt = 0;
     }
+    // Out of work and nearly drained: trace what is left spheres-across-lanes (tail_hit).
+    // Zero or non-finite rays keep to the scan, whose replay has the literal fallback.
+    bool tail = false;
+    if (exhausted) {
+      uint32_t live = 0;
+      bool odd = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        live += __builtin_popcountll(__builtin_amdgcn_ballot_w64(P[r].alive));
+        odd = odd || (P[r].alive && P[r].degenerate);
+      }
+      tail = live <= kTailPaths && __builtin_amdgcn_ballot_w64(odd) == 0;
+    }
     if (MULTI) {
       for (uint32_t base = 0; base < n; base += kChunkSpheres) {
         const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
         __syncthreads();   // every wave is done with the previous chunk
         stage_chunk(p.scene, base, cn, sph, sr2);
         __syncthreads();
-        scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
+        if (!tail) scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
       }
+      if (tail) tail_hit(P, p.scene, lane);
     } else {
-      scan_chunk<STRICT>(P, sph, sr2, n, 0, q, lane, clk);
+      if (tail) tail_hit(P, p.scene, lane);
+      else scan_chunk<STRICT>(P, sph, sr2, n, 0, q, lane, clk);
     }
 
     // ---- the rest of shoot_ray's body ----------------------------------------------------
