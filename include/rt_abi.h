@@ -217,7 +217,8 @@ int rt_get_stats(rt_stats* out);
 int rt_get_launch_ms(uint32_t n_last, float* out_ms);
 
 /* Diagnostic: wave-cycles the last launch spent per phase of its main loop, as
- * out8[0..4] = {refill, scan, replay, shade, steps}.  All zero unless the library was built
+ * out8[0..7] = {refill, scan, replay, shade, steps, drain cycles summed over waves, longest
+ * drain, longest-lived wave}.  All zero unless the library was built
  * with -DRT_DIAG_PHASES (a build for reading shares; its stamps slow the kernel down).
  * No counterpart in the reference. */
 int rt_get_phase_cycles(uint64_t* out8);

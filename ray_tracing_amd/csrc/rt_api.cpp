@@ -127,23 +127,27 @@ std::vector<uint32_t> plan_slices(const rt_frame& f, uint32_t* body_slices) {
   if (f.flags & RT_FLAG_SEQUENTIAL_SUM) {
     sizes.push_back(spp);
   } else {
+    // Full-size items run `big` samples: at most kSamplesPerItem, and no more than ~2 % of what
+    // one lane-slot gets when the frame is split over 8 GPUs (a lane runs an item to its end,
+    // so an item of deep glass paths must stay a small part of a GPU's share of the frame).
+    const uint64_t total = (uint64_t)f.image_width * f.image_height * spp;
+    const uint64_t per_slot_of_8 = total / (8ull * rt::kLaneSlots);
+    uint32_t big = (uint32_t)(per_slot_of_8 / 48);
+    if (big > rt::kSamplesPerItem) big = rt::kSamplesPerItem;
+    if (big < 1) big = 1;
     static const uint32_t taper[8] = {4, 4, 2, 2, 1, 1, 1, 1};   // 16 samples
-    if (spp >= 32) {
-      const uint32_t body = spp - 16;
-      uint32_t big = rt::kSamplesPerItem;
-      const uint32_t room = rt::kMaxSlices - 8 - 1;
-      if ((body + big - 1) / big > room) big = (body + room - 1) / room;
-      for (uint32_t left = body; left > 0;) {
-        const uint32_t n = left < big ? left : big;
-        sizes.push_back(n);
-        left -= n;
-      }
+    const bool use_taper = big > 2 && spp >= 32;
+    const uint32_t body = use_taper ? spp - 16 : spp;
+    const uint32_t room = rt::kMaxSlices - (use_taper ? 8 : 0);
+    if ((body + big - 1) / big > room) big = (body + room - 1) / room;
+    for (uint32_t left = body; left > 0;) {
+      const uint32_t n = left < big ? left : big;
+      sizes.push_back(n);
+      left -= n;
+    }
+    if (use_taper) {
       for (uint32_t t : taper) sizes.push_back(t);
       tail = 8;
-    } else {
-      const uint32_t count = (spp + rt::kSamplesPerItem - 1) / rt::kSamplesPerItem;
-      for (uint32_t k = 0; k < count; ++k)
-        sizes.push_back((uint32_t)(((uint64_t)(k + 1) * spp) / count - ((uint64_t)k * spp) / count));
     }
     // small image: more, equal slices so that every lane has an item
     const uint64_t pixels = (uint64_t)f.image_width * f.image_height;

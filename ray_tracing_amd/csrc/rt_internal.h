@@ -21,6 +21,7 @@ constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic
 constexpr uint32_t kTargetItems = 1u << 20; // below this many pixels, split samples over lanes
 constexpr uint32_t kSamplesPerItem = 8;     // samples one full-size work item runs
 constexpr uint32_t kMaxSlices = 64;         // planes of the partial-sum buffer, at most
+constexpr uint32_t kLaneSlots = 256u * 2u * kThreads * kRaysPerLane;   // paths in flight per GPU
 constexpr uint32_t kTailPaths = 16;         // a wave with no work left and at most this many live
                                             // paths traces them one by one, spheres across lanes
 

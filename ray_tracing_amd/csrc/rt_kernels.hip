@@ -61,6 +61,7 @@ namespace {
 
 struct PhaseClock {
   unsigned long long t0, refill, scan, replay, shade, steps;
+  unsigned long long t_start, t_exhausted, tail_steps;
 };
 
 #ifndef RT_MIN_WAVES
@@ -708,9 +709,10 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
   uint32_t grab_next = 0, grab_end = 0;
   bool exhausted = false;
   uint32_t n_rays = 0, n_samples = 0;
-  PhaseClock clk = {0, 0, 0, 0, 0, 0};
+  PhaseClock clk = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef RT_DIAG_PHASES
   clk.t0 = __builtin_amdgcn_s_memtime();
+  clk.t_start = clk.t0;
 #endif
 
   for (;;) {
@@ -752,6 +754,9 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
     // Out of work and nearly drained: trace what is left spheres-across-lanes (tail_hit).
     // Zero or non-finite rays keep to the scan, whose replay has the literal fallback.
     bool tail = false;
+#ifdef RT_DIAG_PHASES
+    if (exhausted && clk.t_exhausted == 0) clk.t_exhausted = __builtin_amdgcn_s_memtime();
+#endif
     if (exhausted) {
       uint32_t live = 0;
       bool odd = false;
@@ -775,6 +780,9 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
       if (tail) tail_hit(P, p.scene, lane);
       else scan_chunk<STRICT>(P, sph, sr2, n, 0, q, lane, clk);
     }
+#ifdef RT_DIAG_PHASES
+    if (tail) clk.tail_steps++;
+#endif
 
     // ---- the rest of shoot_ray's body ----------------------------------------------------
 #pragma unroll
@@ -820,6 +828,11 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
     atomicAdd(&p.counters->phase[2], clk.replay);
     atomicAdd(&p.counters->phase[3], clk.shade);
     atomicAdd(&p.counters->phase[4], clk.steps);
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    if (clk.t_exhausted == 0) clk.t_exhausted = t_end;
+    atomicAdd(&p.counters->phase[5], t_end - clk.t_exhausted);   // drain time, summed over waves
+    atomicMax(&p.counters->phase[6], t_end - clk.t_exhausted);   // longest drain
+    atomicMax(&p.counters->phase[7], t_end - clk.t_start);       // longest-lived wave
   }
 #endif
   const unsigned long long rays = wave_sum(n_rays);
@@ -897,7 +910,7 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     __syncthreads();
     stage_chunk(p.scene, base, cn, sph, sr2);
     __syncthreads();
-    PhaseClock clk = {0, 0, 0, 0, 0, 0};
+    PhaseClock clk = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
   }
   if (!live) return;

@@ -51,6 +51,9 @@ def main():
               "cycles/step/wave %.0f (steps %d)" % (100 * ph[0] / tot, 100 * ph[1] / tot,
                                                    100 * ph[2] / tot, 100 * ph[3] / tot,
                                                    tot / max(ph[4], 1), int(ph[4])))
+        waves = st.workgroups * st.threads_per_workgroup / 64
+        print("drain after the work queue emptied: mean %.0f kcycles per wave, longest %.0f kcycles; "
+              "longest-lived wave %.0f kcycles" % (ph[5] / waves / 1e3, ph[6] / 1e3, ph[7] / 1e3))
     img = out.cpu().numpy()
     print("mean rgb", np.nanmean(img, axis=(0, 1)), "nan px", int(np.isnan(img).any(axis=2).sum()))
 
