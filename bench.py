@@ -71,6 +71,26 @@ def cpu_baseline(cfg, seed):
     }
 
 
+def profiled_traffic(config, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (profiles/: FETCH_SIZE and WRITE_SIZE, in KiB, each collected in a pass of its own).
+    FETCH_SIZE is doubled as the gfx950 correction for wide reads prescribes, which makes the
+    figure an upper bound for this kernel's narrow reads.  None when no profile of `config` is
+    in the tree: the counters cannot be read from inside a timed run."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "round1", config + "_pmc_per_launch.csv")
+    if not os.path.exists(path):
+        return None
+    kib = {}
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["kernel"] == kernel and row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                kib[row["counter"]] = float(row["value_per_launch"])
+    if len(kib) != 2:
+        return None
+    return int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +99,8 @@ def main():
     ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all on GPU 0, gloo gather through host memory (plumbing check)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -93,12 +115,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
                          "--nproc-per-node %d" % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # --rehearse-on-one-gpu: every rank renders on GPU 0 and the gather goes through gloo and
+    # host memory.  It exercises this file's N > 1 code on a one-GPU box; its numbers mean nothing.
+    rehearsal = args.rehearse_on_one_gpu
+    device_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    hip.init(local_rank)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    hip.init(device_index)
 
     # host side: the reference's scene, camera and request, from the product's host mirror
     W, H, spp, depth = cfg["width"], cfg["height"], cfg["spp"], cfg["depth"]
@@ -110,7 +139,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     plan = multi_gpu.RowPlan(W, H, world)
-    sharded = multi_gpu.ShardedFrame(plan, device, rank)
+    sharded = multi_gpu.ShardedFrame(plan, device, rank, stage_through_host=rehearsal)
     full = torch.zeros((H, W, 3), dtype=torch.float32, device=device) if world == 1 else None
 
     def render_fn(tiles, offs, strides, out):
@@ -123,9 +152,10 @@ def main():
         return sharded.render_and_gather(render_fn)
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -136,7 +166,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -147,6 +177,7 @@ def main():
     flop = FLOP_PER_TEST * n_spheres * st.rays
     achieved = flop / (kernel_ms * 1e-3) * 1e-12 if kernel_ms > 0 else 0.0
 
+    kernel_name = "rt::trace_kernel<false,%s>" % ("true" if n_spheres > 2016 else "false")
     if rank == 0:
         samples_per_step = W * H * spp
         value = samples_per_step * args.steps / elapsed * 1e-6
@@ -163,7 +194,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL on one GPU, not a result",
             "config": {
                 "workload": args.config,
                 "spheres": n_spheres,
@@ -179,8 +210,10 @@ def main():
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                "traffic": None,
-                "kernel": "rt::trace_kernel<false,%s>" % ("true" if n_spheres > 2048 else "false"),
+                "traffic": profiled_traffic(args.config, kernel_name) if world == 1 else None,
+                "traffic_source": "profiles/round1/%s_pmc_per_launch.csv (rocprofv3 --pmc, bytes "
+                                  "per launch of an earlier run of this command)" % args.config,
+                "kernel": kernel_name,
                 "kernel_ms": round(kernel_ms, 3),
                 "rays_per_launch": int(st.rays),
                 "rays_per_sample": round(st.rays / max(st.samples, 1), 4),

@@ -61,15 +61,19 @@ class RowPlan:
 class ShardedFrame:
     """Buffers and index map of one sharded frame; reusable across renders."""
 
-    def __init__(self, plan, device, rank):
+    def __init__(self, plan, device, rank, stage_through_host=False):
+        """`stage_through_host` gathers host copies (for a backend without device collectives,
+        such as gloo driving GPU renders in a rehearsal); RCCL gathers device buffers directly."""
         import torch
         self.plan = plan
         self.rank = rank
+        self.stage_through_host = stage_through_host
         self.local = torch.zeros((plan.rows_per_rank, plan.width, 3), dtype=torch.float32,
                                  device=device)
         self.tiles, self.offsets, self.strides = plan.tiles_for(rank)
         if rank == 0:
-            self.gathered = [torch.zeros_like(self.local) for _ in range(plan.world_size)]
+            like = self.local.cpu() if stage_through_host else self.local
+            self.gathered = [torch.zeros_like(like) for _ in range(plan.world_size)]
             self.row_map = torch.from_numpy(plan.frame_row_map()).to(device)
         else:
             self.gathered = None
@@ -85,6 +89,11 @@ class ShardedFrame:
             render_fn(self.tiles, self.offsets, self.strides, self.local)
         if self.plan.world_size == 1:
             stacked = self.local
+        elif self.stage_through_host:
+            dist.gather(self.local.cpu(), self.gathered, dst=0)   # .cpu() waits for the render
+            if self.rank != 0:
+                return None
+            stacked = torch.stack(self.gathered, dim=0).to(self.local.device)
         else:
             dist.gather(self.local, self.gathered, dst=0)
             if self.rank != 0:

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <cstring>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -144,6 +145,215 @@ __global__ void k_disc_pk(const float4* __restrict__ pairs, int npairs, int reps
   out[tid] = (float)tot;
 }
 
+
+// ---- 4. the conservative 8-instruction discriminant of the production scan, plain and packed
+// over PATH pairs.  Record = (cx, cy, cz, w).  Per path: nd = -d/|d|, od = o.d/|d|, o, noo.
+//   hb = fma(cz,ndz, fma(cy,ndy, fma(cx,ndx, od)));  qh = fma(cz,oz, fma(cy,oy, fma(cx,ox, w)))
+//   disc = fma(hb,hb, fma(qh,2,noo))
+// Plain: 8 VALU per test.  Packed: the two paths of a lane sit in the halves of a register pair
+// and the record's component is broadcast to both halves with op_sel: 8 v_pk_fma_f32 per sphere
+// per path PAIR.  Blocks of 4 spheres, sign bits folded with integer max like the real kernel.
+template <int R>
+__global__ void k_cons(const float4* __restrict__ spheres, int n, int reps, float* out) {
+  extern __shared__ float4 lds[];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = spheres[i];
+  __syncthreads();
+  float ox[R], oy[R], oz[R], nx[R], ny[R], nz[R], od[R], noo[R];
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned h = (tid * R + r) * 2654435761u;
+    ox[r] = 13.f + (h & 255) * 1e-3f; oy[r] = 2.f + ((h >> 8) & 255) * 1e-3f; oz[r] = 3.f;
+    nx[r] = 0.96f - ((h >> 16) & 255) * 1e-3f; ny[r] = 0.15f; nz[r] = 0.22f - (h >> 24) * 1e-3f;
+    od[r] = -(ox[r] * nx[r] + oy[r] * ny[r] + oz[r] * nz[r]);
+    noo[r] = -(ox[r] * ox[r] + oy[r] * oy[r] + oz[r] * oz[r]);
+  }
+  int cnt = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int i = 0; i + 4 <= n; i += 4) {
+      float4 s[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] = lds[i + u];
+      int m = (int)0x80000000;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float hb = __builtin_fmaf(s[u].z, nz[r], __builtin_fmaf(s[u].y, ny[r], __builtin_fmaf(s[u].x, nx[r], od[r])));
+          float qh = __builtin_fmaf(s[u].z, oz[r], __builtin_fmaf(s[u].y, oy[r], __builtin_fmaf(s[u].x, ox[r], s[u].w)));
+          float disc = __builtin_fmaf(hb, hb, __builtin_fmaf(qh, 2.0f, noo[r]));
+          m = max(m, __float_as_int(disc));
+        }
+      }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= 0) != 0, 0)) cnt += (m >= 0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) ox[r] += 1e-6f;
+  }
+  out[tid] = (float)cnt;
+}
+
+// D = S.{lo|hi} (broadcast) * B + C       (C a per-path pair)
+__device__ __forceinline__ f2 pk_lo(f2 s, f2 b, f2 c) {
+  f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(s), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ f2 pk_hi(f2 s, f2 b, f2 c) {
+  f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(s), "v"(b), "v"(c)); return d;
+}
+// D = S.lo (broadcast) * B + T.hi (broadcast)
+__device__ __forceinline__ f2 pk_lo_chi(f2 s, f2 b, f2 t) {
+  f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(s), "v"(b), "v"(t)); return d;
+}
+
+template <int RP, bool ASM>
+__global__ void k_cons_pk(const float4* __restrict__ spheres, int n, int reps, float* out) {
+  extern __shared__ float4 lds[];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = spheres[i];
+  __syncthreads();
+  f2 ox[RP], oy[RP], oz[RP], nx[RP], ny[RP], nz[RP], od[RP], noo[RP];
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < RP; ++p) {
+    float t[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      unsigned h = (tid * 2 * RP + 2 * p + k) * 2654435761u;
+      t[k][0] = 13.f + (h & 255) * 1e-3f; t[k][1] = 2.f + ((h >> 8) & 255) * 1e-3f; t[k][2] = 3.f;
+      t[k][3] = 0.96f - ((h >> 16) & 255) * 1e-3f; t[k][4] = 0.15f; t[k][5] = 0.22f - (h >> 24) * 1e-3f;
+      t[k][6] = -(t[k][0] * t[k][3] + t[k][1] * t[k][4] + t[k][2] * t[k][5]);
+      t[k][7] = -(t[k][0] * t[k][0] + t[k][1] * t[k][1] + t[k][2] * t[k][2]);
+    }
+    ox[p] = f2{t[0][0], t[1][0]}; oy[p] = f2{t[0][1], t[1][1]}; oz[p] = f2{t[0][2], t[1][2]};
+    nx[p] = f2{t[0][3], t[1][3]}; ny[p] = f2{t[0][4], t[1][4]}; nz[p] = f2{t[0][5], t[1][5]};
+    od[p] = f2{t[0][6], t[1][6]}; noo[p] = f2{t[0][7], t[1][7]};
+  }
+  int cnt = 0;
+  const f2 two = {2.0f, 2.0f};
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int i = 0; i + 4 <= n; i += 4) {
+      float4 s[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] = lds[i + u];
+      int m = (int)0x80000000;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f2 sxy = {s[u].x, s[u].y}, szw = {s[u].z, s[u].w};
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+          f2 hb, qh, disc;
+          if (ASM) {
+            hb = pk_lo(szw, nz[p], pk_hi(sxy, ny[p], pk_lo(sxy, nx[p], od[p])));
+            qh = pk_lo(szw, oz[p], pk_hi(sxy, oy[p], pk_lo_chi(sxy, ox[p], szw)));
+          } else {
+            hb = __builtin_elementwise_fma(f2(s[u].z), nz[p], __builtin_elementwise_fma(f2(s[u].y), ny[p],
+                 __builtin_elementwise_fma(f2(s[u].x), nx[p], od[p])));
+            qh = __builtin_elementwise_fma(f2(s[u].z), oz[p], __builtin_elementwise_fma(f2(s[u].y), oy[p],
+                 __builtin_elementwise_fma(f2(s[u].x), ox[p], f2(s[u].w))));
+          }
+          disc = __builtin_elementwise_fma(hb, hb, __builtin_elementwise_fma(qh, two, noo[p]));
+          m = max(m, max(__float_as_int(disc.x), __float_as_int(disc.y)));
+        }
+      }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= 0) != 0, 0)) cnt += (m >= 0);
+    }
+#pragma unroll
+    for (int p = 0; p < RP; ++p) ox[p] += 1e-6f;
+  }
+  out[tid] = (float)cnt;
+}
+
+
+// ---- 5. the same discriminant with the matrix pipe doing part of the work.
+// v_mfma_f32_16x16x4_f32 is bit-for-bit the k-ordered fmaf chain, so with A = (1|w, cx, cy, cz)
+// per sphere and B = (od|1, ndx|ox, ndy|oy, ndz|oz) per ray it produces exactly the hb and qh of
+// the plain form for a 16-sphere x 16-ray tile, in the C/D layout (col = ray = lane & 15,
+// row = sphere = 4 * (lane >> 4) + reg).  MODE 0: every ray through MFMA (NT tiles of 16 rays per
+// wave).  MODE 1: additionally one ray per lane through the plain VALU form (the two pipes run
+// side by side).
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int NT, int MODE>
+__global__ void k_mix(const float4* __restrict__ spheres, int n, int reps, float* out) {
+  extern __shared__ float4 lds[];
+  float* ah = reinterpret_cast<float*>(lds + n);        // [block][64]
+  float* aq = ah + (n / 16) * 64;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[i] = spheres[i];
+  for (int e = threadIdx.x; e < (n / 16) * 64; e += blockDim.x) {
+    const int b = e / 64, l = e % 64, i = b * 16 + (l & 15), k = l >> 4;
+    const float4 s = spheres[i];
+    const float comp = k == 1 ? s.x : k == 2 ? s.y : s.z;
+    ah[e] = k == 0 ? 1.0f : comp;
+    aq[e] = k == 0 ? s.w : comp;
+  }
+  __syncthreads();
+  const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned lane = threadIdx.x & 63;
+  // classic ray of this lane
+  float ox, oy, oz, nx, ny, nz, od, noo;
+  {
+    unsigned h = tid * 2654435761u;
+    ox = 13.f + (h & 255) * 1e-3f; oy = 2.f + ((h >> 8) & 255) * 1e-3f; oz = 3.f;
+    nx = 0.96f - ((h >> 16) & 255) * 1e-3f; ny = 0.15f; nz = 0.22f - (h >> 24) * 1e-3f;
+    od = -(ox * nx + oy * ny + oz * nz);
+    noo = -(ox * ox + oy * oy + oz * oz);
+  }
+  // B operands of the NT ray tiles: component (lane >> 4) of ray (lane & 15) of the tile
+  float bh[NT], bq[NT], tn[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    unsigned h = ((tid & ~63u) * NT + t * 16 + (lane & 15)) * 2246822519u + 12345u;
+    float rx = 13.f + (h & 255) * 1e-3f, ry = 2.f + ((h >> 8) & 255) * 1e-3f, rz = 3.f;
+    float mx = 0.96f - ((h >> 16) & 255) * 1e-3f, my = 0.15f, mz = 0.22f - (h >> 24) * 1e-3f;
+    float rod = -(rx * mx + ry * my + rz * mz);
+    const int k = lane >> 4;
+    bh[t] = k == 0 ? rod : k == 1 ? mx : k == 2 ? my : mz;
+    bq[t] = k == 0 ? 1.0f : k == 1 ? rx : k == 2 ? ry : rz;
+    tn[t] = -(rx * rx + ry * ry + rz * rz);
+  }
+  int cnt = 0;
+  const f4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int b = 0; b + 1 <= n / 16; ++b) {
+      const float a_h = ah[b * 64 + lane], a_q = aq[b * 64 + lane];
+      int m = (int)0x80000000;
+      f4 dh[NT], dq[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        dh[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_h, bh[t], zero, 0, 0, 0);
+        dq[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_q, bq[t], zero, 0, 0, 0);
+      }
+      if (MODE == 1) {
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+          float4 s[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) s[u] = lds[b * 16 + u4 * 4 + u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float hb = __builtin_fmaf(s[u].z, nz, __builtin_fmaf(s[u].y, ny, __builtin_fmaf(s[u].x, nx, od)));
+            float qh = __builtin_fmaf(s[u].z, oz, __builtin_fmaf(s[u].y, oy, __builtin_fmaf(s[u].x, ox, s[u].w)));
+            float disc = __builtin_fmaf(hb, hb, __builtin_fmaf(qh, 2.0f, noo));
+            m = max(m, __float_as_int(disc));
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float disc = __builtin_fmaf(dh[t][e], dh[t][e], __builtin_fmaf(dq[t][e], 2.0f, tn[t]));
+          m = max(m, __float_as_int(disc));
+        }
+      }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= 0) != 0, 0)) cnt += (m >= 0);
+    }
+    ox += 1e-6f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tn[t] -= 1e-6f;
+  }
+  out[tid] = (float)cnt;
+}
+
 static float time_ms(hipEvent_t e0, hipEvent_t e1) { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
 
 int main(int argc, char** argv) {
@@ -154,6 +364,73 @@ int main(int argc, char** argv) {
          p.sharedMemPerBlock, p.gcnArchName);
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float* out; CK(hipMalloc(&out, sizeof(float) * 256 * 1024 * 8));
+
+
+  if (argc > 2 && !strcmp(argv[2], "cons")) {
+    const int n = 488, reps = 400;
+    std::vector<float4> hs(n);
+    // w chosen so that no discriminant is ever >= 0 (pure scan cost, like most blocks)
+    for (int i = 0; i < n; ++i) hs[i] = make_float4((i % 22) - 11 + 0.3f, 0.2f, (i / 22) - 11 + 0.4f, -1e6f);
+    float4* ds; CK(hipMalloc(&ds, sizeof(float4) * n));
+    CK(hipMemcpy(ds, hs.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    auto run = [&](const char* name, auto kern, int R, int wps, int threads) {
+      int blocks = cus * wps * 256 / threads;
+      float best = 1e30f;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), n * sizeof(float4), 0, ds, n, reps, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms = time_ms(e0, e1);
+        if (ms < best) best = ms;
+      }
+      CK(hipGetLastError());
+      double tests = (double)blocks * threads * R * n * reps;
+      printf("%-12s paths/lane %d waves/SIMD %d : %8.3f ms  %7.2f Gtests/s  = %5.1f%% of 157.3 TF at 17 flop/test\n",
+             name, R, wps, best, tests / best * 1e-6, tests * 17 / best * 1e-9 / 157.3 * 100);
+    };
+    for (int wps : {2, 4, 8}) {
+      run("cons", k_cons<2>, 2, wps, 256);
+      run("cons", k_cons<4>, 4, wps, 256);
+      run("cons_pk", (k_cons_pk<1, false>), 2, wps, 256);
+      run("cons_pk", (k_cons_pk<2, false>), 4, wps, 256);
+      run("cons_pk_asm", (k_cons_pk<1, true>), 2, wps, 256);
+      run("cons_pk_asm", (k_cons_pk<2, true>), 4, wps, 256);
+    }
+    return 0;
+  }
+
+
+  if (argc > 2 && !strcmp(argv[2], "mix")) {
+    const int n = 480, reps = 400;
+    std::vector<float4> hs(n);
+    for (int i = 0; i < n; ++i) hs[i] = make_float4((i % 22) - 11 + 0.3f, 0.2f, (i / 22) - 11 + 0.4f, -1e6f);
+    float4* ds; CK(hipMalloc(&ds, sizeof(float4) * n));
+    CK(hipMemcpy(ds, hs.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    auto run = [&](const char* name, auto kern, int rays_per_wave, int wps, int threads) {
+      int blocks = cus * wps * 256 / threads;
+      float best = 1e30f;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), n * sizeof(float4) * 3, 0, ds, n, reps, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms = time_ms(e0, e1);
+        if (ms < best) best = ms;
+      }
+      CK(hipGetLastError());
+      double tests = (double)blocks * (threads / 64) * rays_per_wave * n * reps;
+      printf("%-12s rays/wave %3d waves/SIMD %d : %8.3f ms  %7.2f Gtests/s  = %5.1f%% of 157.3 TF at 17 flop/test\n",
+             name, rays_per_wave, wps, best, tests / best * 1e-6, tests * 17 / best * 1e-9 / 157.3 * 100);
+    };
+    for (int wps : {1, 2, 4}) {
+      run("cons", k_cons<2>, 128, wps, 256);
+      run("mfma4", (k_mix<4, 0>), 64, wps, 256);
+      run("mfma8", (k_mix<8, 0>), 128, wps, 256);
+      run("mix1+4", (k_mix<4, 1>), 128, wps, 256);
+      run("mix1+8", (k_mix<8, 1>), 192, wps, 256);
+      run("mix1+6", (k_mix<6, 1>), 160, wps, 256);
+    }
+    return 0;
+  }
 
   // --- 1. fma vs pk_fma
   const int iters = 4096;
