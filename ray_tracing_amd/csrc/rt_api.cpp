@@ -49,24 +49,59 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 constexpr int kEventRing = 64;
+constexpr int kLaunchSlots = 4;
+
+// What one in-flight render owns on the device.  Launches on the same stream run one after the
+// other and share a slot; launches on different streams may overlap on the GPU, so each stream
+// gets a slot of its own.  With more streams than slots the least recently used slot is
+// recycled after waiting for its stream.
+struct LaunchSlot {
+  hipStream_t stream = nullptr;
+  bool bound = false;
+  rt::Counters* counters = nullptr;       // device
+  float* partial = nullptr;               // device, grow-only: per-slice sums
+  size_t partial_cap = 0;                 // in floats
+  uint64_t last_use = 0;
+  rt_stats last = {};
+  int event = -1;                         // index in the event ring of the slot's last launch
+};
 
 struct State {
   bool ready = false;
   int device = -1;
   int cus = 0;
   hipStream_t stream = nullptr;
-  rt::Counters* counters = nullptr;       // device
+  LaunchSlot slots[kLaunchSlots];
+  int last_slot = -1;
   rt::TileDev* tiles = nullptr;           // device, grow-only
   size_t tiles_cap = 0;
   std::vector<rt::TileDev> tiles_host;    // what g.tiles currently holds
-  float* partial = nullptr;               // device, grow-only: per-slice sums
-  size_t partial_cap = 0;                 // in floats
   hipEvent_t ev_begin[kEventRing], ev_end[kEventRing];
   uint64_t launches = 0;
-  rt_stats last = {};
-  hipStream_t last_stream = nullptr;
 };
 State g;
+
+int acquire_slot(hipStream_t stream, LaunchSlot** out) {
+  int pick = -1;
+  for (int i = 0; i < kLaunchSlots; ++i)
+    if (g.slots[i].bound && g.slots[i].stream == stream) pick = i;
+  if (pick < 0) {
+    for (int i = 0; i < kLaunchSlots && pick < 0; ++i)
+      if (!g.slots[i].bound) pick = i;
+    if (pick < 0) {
+      pick = 0;
+      for (int i = 1; i < kLaunchSlots; ++i)
+        if (g.slots[i].last_use < g.slots[pick].last_use) pick = i;
+      RT_HIP(hipStreamSynchronize(g.slots[pick].stream));   // its buffers may still be in use
+    }
+    g.slots[pick].stream = stream;
+    g.slots[pick].bound = true;
+  }
+  g.slots[pick].last_use = g.launches + 1;
+  g.last_slot = pick;
+  *out = &g.slots[pick];
+  return RT_OK;
+}
 
 // Per-sphere constant of the kernel's conservative discriminant scan.
 //
@@ -202,16 +237,18 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   p.total_items = (uint32_t)(total_pixels * p.slices);
   p.out_pixels = out_pixels;
   p.inv_spp = 1.0f / (float)frame->samples_per_pixel;   // `1.0 / spp as f32`, src/cpu/mod.rs:67
-  p.counters = g.counters;
+  LaunchSlot* slot = nullptr;
+  if (int rc = acquire_slot(stream, &slot)) return rc;
+  p.counters = slot->counters;
 
   const bool strict = (frame->flags & RT_FLAG_STRICT_FP) != 0;
 
   if (frame->max_depth == 0) {
     // shoot_ray(ray, 0) is black (src/main.rs:192-194): every sum is 0 and nothing is traced
     RT_HIP(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(float), stream));
-    g.last = {};
-    g.last.samples = total_pixels * frame->samples_per_pixel;
-    g.last_stream = stream;
+    slot->last = {};
+    slot->last.samples = total_pixels * frame->samples_per_pixel;
+    slot->event = -1;
     return RT_OK;
   }
 
@@ -243,15 +280,15 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   float* trace_out = d_out;
   if (p.slices > 1) {
     const size_t need = (size_t)out_pixels * 3 * p.slices;
-    if (need > g.partial_cap) {
-      RT_HIP(hipDeviceSynchronize());
-      if (g.partial) RT_HIP(hipFree(g.partial));
-      g.partial = nullptr;
-      g.partial_cap = 0;
-      RT_HIP(hipMalloc((void**)&g.partial, need * sizeof(float)));
-      g.partial_cap = need;
+    if (need > slot->partial_cap) {
+      RT_HIP(hipStreamSynchronize(stream));   // the slot's earlier launches read the old buffer
+      if (slot->partial) RT_HIP(hipFree(slot->partial));
+      slot->partial = nullptr;
+      slot->partial_cap = 0;
+      RT_HIP(hipMalloc((void**)&slot->partial, need * sizeof(float)));
+      slot->partial_cap = need;
     }
-    trace_out = g.partial;
+    trace_out = slot->partial;
     p.resolve = 0;
   } else {
     p.resolve = resolve;
@@ -269,16 +306,17 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
   if (blocks < 1) blocks = 1;
 
-  RT_HIP(hipMemsetAsync(g.counters, 0, sizeof(rt::Counters), stream));
-  const int slot = (int)(g.launches % kEventRing);
-  RT_HIP(hipEventRecord(g.ev_begin[slot], stream));
+  RT_HIP(hipMemsetAsync(slot->counters, 0, sizeof(rt::Counters), stream));
+  const int ev = (int)(g.launches % kEventRing);
+  RT_HIP(hipEventRecord(g.ev_begin[ev], stream));
   RT_HIP(rt::launch_trace(p, strict, blocks, stream));
-  RT_HIP(hipEventRecord(g.ev_end[slot], stream));
+  RT_HIP(hipEventRecord(g.ev_end[ev], stream));
   g.launches++;
+  slot->event = ev;
 
   if (p.slices > 1) {
     rt::ReduceParams rp;
-    rp.partial = g.partial;
+    rp.partial = slot->partial;
     rp.out = d_out;
     rp.out_pixels = out_pixels;
     rp.slices = p.slices;
@@ -291,13 +329,12 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
     RT_HIP(rt::launch_reduce(rp, stream));
   }
 
-  g.last = {};
-  g.last.rays_per_lane = rt::kRaysPerLane;
-  g.last.slices = p.slices;
-  g.last.workgroups = (uint32_t)blocks;
-  g.last.threads_per_workgroup = rt::kThreads;
-  g.last.sphere_tests = scene->dev.n_spheres;   // multiplied by rays in rt_get_stats
-  g.last_stream = stream;
+  slot->last = {};
+  slot->last.rays_per_lane = rt::kRaysPerLane;
+  slot->last.slices = p.slices;
+  slot->last.workgroups = (uint32_t)blocks;
+  slot->last.threads_per_workgroup = rt::kThreads;
+  slot->last.sphere_tests = scene->dev.n_spheres;   // multiplied by rays in rt_get_stats
   return RT_OK;
 }
 
@@ -365,8 +402,10 @@ int rt_init(int device) {
                 prop.gcnArchName);
   g.cus = prop.multiProcessorCount;
   RT_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-  RT_HIP(hipMalloc((void**)&g.counters, sizeof(rt::Counters)));
-  RT_HIP(hipMemset(g.counters, 0, sizeof(rt::Counters)));
+  for (LaunchSlot& sl : g.slots) {
+    RT_HIP(hipMalloc((void**)&sl.counters, sizeof(rt::Counters)));
+    RT_HIP(hipMemset(sl.counters, 0, sizeof(rt::Counters)));
+  }
   for (int i = 0; i < kEventRing; ++i) {
     RT_HIP(hipEventCreate(&g.ev_begin[i]));
     RT_HIP(hipEventCreate(&g.ev_end[i]));
@@ -385,9 +424,11 @@ int rt_shutdown(void) {
     (void)hipEventDestroy(g.ev_begin[i]);
     (void)hipEventDestroy(g.ev_end[i]);
   }
-  if (g.counters) (void)hipFree(g.counters);
+  for (LaunchSlot& sl : g.slots) {
+    if (sl.counters) (void)hipFree(sl.counters);
+    if (sl.partial) (void)hipFree(sl.partial);
+  }
   if (g.tiles) (void)hipFree(g.tiles);
-  if (g.partial) (void)hipFree(g.partial);
   if (g.stream) (void)hipStreamDestroy(g.stream);
   g = State();
   return RT_OK;
@@ -529,30 +570,38 @@ int rt_synchronize(void* stream) {
 int rt_get_stats(rt_stats* out) {
   if (int rc = check_ready()) return rc;
   if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
-  RT_HIP(hipStreamSynchronize(g.last_stream ? g.last_stream : g.stream));
-  rt_stats s = g.last;
+  if (g.last_slot < 0) {
+    *out = rt_stats{};
+    return RT_OK;
+  }
+  const LaunchSlot& sl = g.slots[g.last_slot];
+  RT_HIP(hipStreamSynchronize(sl.stream));
+  rt_stats s = sl.last;
   if (s.workgroups != 0) {
     rt::Counters c;
-    RT_HIP(hipMemcpy(&c, g.counters, sizeof c, hipMemcpyDeviceToHost));
+    RT_HIP(hipMemcpy(&c, sl.counters, sizeof c, hipMemcpyDeviceToHost));
     s.rays = c.rays;
     s.samples = c.samples;
-    s.sphere_tests = c.rays * g.last.sphere_tests;
-    const int slot = (int)((g.launches - 1) % kEventRing);
+    s.sphere_tests = c.rays * sl.last.sphere_tests;
     float ms = 0.0f;
-    RT_HIP(hipEventElapsedTime(&ms, g.ev_begin[slot], g.ev_end[slot]));
+    RT_HIP(hipEventElapsedTime(&ms, g.ev_begin[sl.event], g.ev_end[sl.event]));
     s.kernel_ms = ms;
   }
   *out = s;
   return RT_OK;
 }
 
-int rt_get_phase_cycles(uint64_t* out8) {
+int rt_get_phase_cycles(uint64_t* out16) {
   if (int rc = check_ready()) return rc;
-  if (!out8) return fail(RT_ERR_INVALID_ARGUMENT, "out8 is NULL");
-  RT_HIP(hipStreamSynchronize(g.last_stream ? g.last_stream : g.stream));
+  if (!out16) return fail(RT_ERR_INVALID_ARGUMENT, "out16 is NULL");
   rt::Counters c;
-  RT_HIP(hipMemcpy(&c, g.counters, sizeof c, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 8; ++i) out8[i] = c.phase[i];
+  memset(&c, 0, sizeof c);
+  if (g.last_slot >= 0) {
+    const LaunchSlot& sl = g.slots[g.last_slot];
+    RT_HIP(hipStreamSynchronize(sl.stream));
+    RT_HIP(hipMemcpy(&c, sl.counters, sizeof c, hipMemcpyDeviceToHost));
+  }
+  for (int i = 0; i < 16; ++i) out16[i] = c.phase[i];
   return RT_OK;
 }
 

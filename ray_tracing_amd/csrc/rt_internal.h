@@ -20,10 +20,17 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic
 constexpr uint32_t kTargetItems = 1u << 20; // below this many pixels, split samples over lanes
 constexpr uint32_t kSamplesPerItem = 8;     // samples one full-size work item runs
-constexpr uint32_t kMaxSlices = 64;         // planes of the partial-sum buffer, at most
+#ifndef RT_MAX_SLICES
+#define RT_MAX_SLICES 64
+#endif
+constexpr uint32_t kMaxSlices = RT_MAX_SLICES;  // planes of the partial-sum buffer, at most
 constexpr uint32_t kLaneSlots = 256u * 2u * kThreads * kRaysPerLane;   // paths in flight per GPU
-constexpr uint32_t kTailPaths = 16;         // a wave with no work left and at most this many live
-                                            // paths traces them one by one, spheres across lanes
+#ifndef RT_TAIL_PATHS
+#define RT_TAIL_PATHS 16
+#endif
+constexpr uint32_t kTailPaths = RT_TAIL_PATHS;  // a wave with no work left and at most this many
+                                                // live paths traces them with the spheres spread
+                                                // across its lanes
 
 // One tile of the request as the kernel sees it.
 struct TileDev {
@@ -53,9 +60,9 @@ struct Counters {
   uint32_t pad;
   unsigned long long rays;     // World::hit calls
   unsigned long long samples;  // shoot_ray calls from the pixel loop
-  // Wave-cycles per phase (refill, scan, replay, shade, steps); filled only by a build with
-  // -DRT_DIAG_PHASES, whose timings are for shares, not for speed.
-  unsigned long long phase[8];
+  // Wave-cycles per phase and drain statistics (see rt_get_phase_cycles); filled only by a
+  // build with -DRT_DIAG_PHASES, whose timings are for shares, not for speed.
+  unsigned long long phase[16];
 };
 
 struct TraceParams {

@@ -62,6 +62,7 @@ namespace {
 struct PhaseClock {
   unsigned long long t0, refill, scan, replay, shade, steps;
   unsigned long long t_start, t_exhausted, tail_steps;
+  unsigned long long drain_scan_steps, tail_cycles;
 };
 
 #ifndef RT_MIN_WAVES
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
   uint32_t grab_next = 0, grab_end = 0;
   bool exhausted = false;
   uint32_t n_rays = 0, n_samples = 0;
-  PhaseClock clk = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  PhaseClock clk = {};
 #ifdef RT_DIAG_PHASES
   clk.t0 = __builtin_amdgcn_s_memtime();
   clk.t_start = clk.t0;
@@ -782,6 +783,8 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
     }
 #ifdef RT_DIAG_PHASES
     if (tail) clk.tail_steps++;
+    else if (exhausted) clk.drain_scan_steps++;
+    if (tail) clk.tail_cycles += __builtin_amdgcn_s_memtime() - clk.t0;
 #endif
 
     // ---- the rest of shoot_ray's body ----------------------------------------------------
@@ -833,6 +836,12 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
     atomicAdd(&p.counters->phase[5], t_end - clk.t_exhausted);   // drain time, summed over waves
     atomicMax(&p.counters->phase[6], t_end - clk.t_exhausted);   // longest drain
     atomicMax(&p.counters->phase[7], t_end - clk.t_start);       // longest-lived wave
+    atomicAdd(&p.counters->phase[8], clk.drain_scan_steps);      // drain steps that scanned
+    atomicAdd(&p.counters->phase[9], clk.tail_steps);            // drain steps in tail mode
+    atomicMax(&p.counters->phase[10], clk.drain_scan_steps);
+    atomicMax(&p.counters->phase[11], clk.tail_steps);
+    atomicAdd(&p.counters->phase[12], clk.tail_cycles);          // cycles inside tail_hit
+    atomicAdd(&p.counters->phase[13], 1ull);                     // waves
   }
 #endif
   const unsigned long long rays = wave_sum(n_rays);
@@ -910,7 +919,7 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     __syncthreads();
     stage_chunk(p.scene, base, cn, sph, sr2);
     __syncthreads();
-    PhaseClock clk = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    PhaseClock clk = {};
     scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
   }
   if (!live) return;

@@ -219,7 +219,7 @@ def get_launch_ms(n_last):
 
 
 def get_phase_cycles():
-    out = np.zeros(8, dtype=np.uint64)
+    out = np.zeros(16, dtype=np.uint64)
     check(lib().rt_get_phase_cycles(abi.ptr(out)))
     return out
 
