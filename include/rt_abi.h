@@ -206,6 +206,26 @@ int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame,
                                 uint32_t row_begin, uint32_t row_end,
                                 int resolve, float* d_out, void* stream);
 
+/* Progressive rendering: adds samples [sample_begin, sample_begin + frame->samples_per_pixel)
+ * of every covered pixel to the UN-NORMALISED sums d_sums already holds (same addressing as
+ * rt_render_device_async with resolve = 0).  A sample's random stream is keyed by its absolute
+ * index, so passes that cover [0, S) between them draw exactly the paths of one S-sample render.
+ * With RT_FLAG_SEQUENTIAL_SUM every pass carries the per-pixel running sum on in sample order
+ * and the result is bit-identical to that one render; otherwise a pass adds its own sum
+ * (sliced like a render of its length) to the buffer in one addition.  The contract it builds on
+ * is the additive JobResult.pixel_colors of src/cpu/job.rs:48-61 with the division by the
+ * sample count left to compose_final_framebuffer (src/cpu/mod.rs:67); the reference itself
+ * renders in one pass. */
+int rt_accumulate_device_async(const rt_scene* scene, const rt_frame* frame, uint32_t sample_begin,
+                               const rt_tile* tiles, const uint64_t* out_offset,
+                               const uint32_t* out_stride, uint32_t n_tiles, float* d_sums,
+                               void* stream);
+
+/* compose_final_framebuffer's arithmetic (src/cpu/mod.rs:67-75), x*(1/spp), sqrt, clamp, over
+ * n_pixels RGB sums in device memory; d_rgb may be d_sums. */
+int rt_resolve_device_async(const float* d_sums, uint64_t n_pixels, uint32_t samples_per_pixel,
+                            float* d_rgb, void* stream);
+
 int rt_synchronize(void* stream);
 int rt_get_stats(rt_stats* out);
 

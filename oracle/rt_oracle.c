@@ -487,6 +487,48 @@ void ro_execute_job(const rt_tile* job, const ro_job_data* data, float* out, ro_
   }
 }
 
+/* The sample loop of execute_job (src/cpu/job.rs:48-61) carried on from an existing sum:
+ * `inout` holds the tile's sums after samples [0, sample_begin) and receives them after samples
+ * [0, sample_begin + n_samples), `pixel_color += color` continuing in sample order.  The
+ * reference renders in one pass; this is the same loop cut in two, so running it over
+ * [0, a) and then [a, b) gives bit for bit what ro_execute_job gives for b samples. */
+void ro_accumulate_job(const rt_tile* job, const ro_job_data* data, uint32_t sample_begin,
+                       uint32_t n_samples, float* inout, ro_counters* ctr) {
+  uint32_t image_width = data->image_width;
+  uint32_t image_height = data->image_height;
+  size_t k = 0;
+  for (uint32_t yoff = 0; yoff < job->height; ++yoff) {
+    for (uint32_t xoff = 0; xoff < job->width; ++xoff) {
+      uint32_t x = job->x + xoff;
+      uint32_t y = job->y + yoff;
+      ro_vec3 pixel_color = v3(inout[3 * k + 0], inout[3 * k + 1], inout[3 * k + 2]);
+      for (uint32_t sample = sample_begin; sample < sample_begin + n_samples; ++sample) {
+        ro_rng rng;
+        ro_rng_counter(&rng, data->seed, y * image_width + x, sample);
+        float u = ((float)x + ro_random_f32(&rng)) / (float)image_width;
+        float v = ((float)y + ro_random_f32(&rng)) / (float)image_height;
+        u = u * 2.0f - 1.0f;
+        v = v * 2.0f - 1.0f;
+        ro_ray ray = ro_camera_get_ray(data->camera, u, v);
+        ro_vec3 color;
+        if (data->mode == RO_MODE_RECURSIVE) {
+          color = ro_shoot_ray(data->world, &ray, data->max_depth, &rng, ctr);
+        } else {
+          color = ro_shoot_ray_iter(data->world, &ray, data->max_depth, &rng,
+                                    data->mode == RO_MODE_ITER_MUL ? RO_POW5_MUL : RO_POW5_LIBM,
+                                    ctr);
+        }
+        if (ctr) ctr->samples++;
+        pixel_color = v3_add(pixel_color, color);
+      }
+      inout[3 * k + 0] = pixel_color.x;
+      inout[3 * k + 1] = pixel_color.y;
+      inout[3 * k + 2] = pixel_color.z;
+      k++;
+    }
+  }
+}
+
 /* create_job_queue, src/cpu/job.rs:76-152: full tiles row-major, bottom strip, right strip,
  * corner.  The corner's start_y uses tile_width (src/cpu/job.rs:140), kept as written. */
 uint32_t ro_create_job_queue(uint32_t image_width, uint32_t image_height, uint32_t tile_width,

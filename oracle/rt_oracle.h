@@ -131,6 +131,10 @@ typedef struct ro_job_data {
 
 /* execute_job: out receives tile->width*tile->height RGB sums, row-major inside the tile. */
 void ro_execute_job(const rt_tile* job, const ro_job_data* data, float* out, ro_counters* ctr);
+/* execute_job's sample loop continued from the sums in `inout`: samples
+ * [sample_begin, sample_begin + n_samples) are added in order. */
+void ro_accumulate_job(const rt_tile* job, const ro_job_data* data, uint32_t sample_begin,
+                       uint32_t n_samples, float* inout, ro_counters* ctr);
 /* create_job_queue: returns the number of jobs; writes at most cap of them. */
 uint32_t ro_create_job_queue(uint32_t image_width, uint32_t image_height, uint32_t tile_width,
                              uint32_t tile_height, rt_tile* out, uint32_t cap);

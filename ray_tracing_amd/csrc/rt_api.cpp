@@ -202,9 +202,12 @@ std::vector<uint32_t> plan_slices(const rt_frame& f, uint32_t* body_slices) {
   return begin;
 }
 
+// `sample_begin` / `accumulate`: the call adds samples [sample_begin, sample_begin + spp) of
+// every pixel to what d_out already holds (progressive rendering; resolve must be 0).
 int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
                         const std::vector<rt::TileDev>& tiles, uint64_t out_pixels, int resolve,
-                        float* d_out, hipStream_t stream) {
+                        float* d_out, hipStream_t stream, uint32_t sample_begin = 0,
+                        bool accumulate = false) {
   rt::TraceParams p;
   memset(&p, 0, sizeof p);
   p.scene = scene->dev;
@@ -226,7 +229,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   p.seed_b = rt_rng_seed_b(frame->seed);
   const std::vector<uint32_t> slice_begin = plan_slices(*frame, &p.body_slices);
   p.slices = (uint32_t)slice_begin.size() - 1;
-  for (size_t k = 0; k < slice_begin.size(); ++k) p.slice_begin[k] = slice_begin[k];
+  for (size_t k = 0; k < slice_begin.size(); ++k) p.slice_begin[k] = sample_begin + slice_begin[k];
   p.n_tiles = (uint32_t)tiles.size();
   uint64_t total_pixels = 0;
   for (const rt::TileDev& t : tiles) total_pixels += (uint64_t)t.w * t.h;
@@ -245,7 +248,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
 
   if (frame->max_depth == 0) {
     // shoot_ray(ray, 0) is black (src/main.rs:192-194): every sum is 0 and nothing is traced
-    RT_HIP(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(float), stream));
+    if (!accumulate) RT_HIP(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(float), stream));
     slot->last = {};
     slot->last.samples = total_pixels * frame->samples_per_pixel;
     slot->event = -1;
@@ -292,6 +295,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
     p.resolve = 0;
   } else {
     p.resolve = resolve;
+    p.accumulate = accumulate ? 1 : 0;
   }
   p.out = trace_out;
 
@@ -325,6 +329,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
     rp.tile0 = p.tile0;
     rp.tiles = p.tiles;
     rp.resolve = resolve;
+    rp.accumulate = accumulate ? 1 : 0;
     rp.inv_spp = p.inv_spp;
     RT_HIP(rt::launch_reduce(rp, stream));
   }
@@ -507,17 +512,12 @@ int rt_scene_destroy(rt_scene* scene) {
   return RT_OK;
 }
 
-int rt_render_device_async(const rt_scene* scene, const rt_frame* frame, const rt_tile* tiles,
-                           const uint64_t* out_offset, const uint32_t* out_stride,
-                           uint32_t n_tiles, int resolve, float* d_out, void* stream) {
-  if (int rc = check_ready()) return rc;
-  if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
-  if (int rc = check_frame(frame)) return rc;
-  if (n_tiles == 0) return RT_OK;
-  if (!tiles || !out_offset || !out_stride || !d_out)
-    return fail(RT_ERR_INVALID_ARGUMENT, "NULL tile table or output");
+namespace {
+int tile_table(const rt_frame* frame, const rt_tile* tiles, const uint64_t* out_offset,
+               const uint32_t* out_stride, uint32_t n_tiles, std::vector<rt::TileDev>* out_td,
+               uint64_t* out_pixels_total) {
   if (int rc = check_tiles(tiles, n_tiles, frame->image_width, frame->image_height)) return rc;
-  std::vector<rt::TileDev> td;
+  std::vector<rt::TileDev>& td = *out_td;
   td.reserve(n_tiles);
   uint64_t first = 0, out_pixels = 0;
   for (uint32_t i = 0; i < n_tiles; ++i) {
@@ -536,8 +536,59 @@ int rt_render_device_async(const rt_scene* scene, const rt_frame* frame, const r
     if (end > out_pixels) out_pixels = end;
     td.push_back(t);
   }
+  *out_pixels_total = out_pixels;
+  return RT_OK;
+}
+}  // namespace
+
+int rt_render_device_async(const rt_scene* scene, const rt_frame* frame, const rt_tile* tiles,
+                           const uint64_t* out_offset, const uint32_t* out_stride,
+                           uint32_t n_tiles, int resolve, float* d_out, void* stream) {
+  if (int rc = check_ready()) return rc;
+  if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  if (int rc = check_frame(frame)) return rc;
+  if (n_tiles == 0) return RT_OK;
+  if (!tiles || !out_offset || !out_stride || !d_out)
+    return fail(RT_ERR_INVALID_ARGUMENT, "NULL tile table or output");
+  std::vector<rt::TileDev> td;
+  uint64_t out_pixels = 0;
+  if (int rc = tile_table(frame, tiles, out_offset, out_stride, n_tiles, &td, &out_pixels)) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : g.stream;
   return render_tiles_device(scene, frame, td, out_pixels, resolve, d_out, s);
+}
+
+int rt_accumulate_device_async(const rt_scene* scene, const rt_frame* frame, uint32_t sample_begin,
+                               const rt_tile* tiles, const uint64_t* out_offset,
+                               const uint32_t* out_stride, uint32_t n_tiles, float* d_sums,
+                               void* stream) {
+  if (int rc = check_ready()) return rc;
+  if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  if (int rc = check_frame(frame)) return rc;
+  if ((uint64_t)sample_begin + frame->samples_per_pixel > 0xFFFFFFFFull)
+    return fail(RT_ERR_LIMIT, "sample index beyond 2^32");
+  if (n_tiles == 0) return RT_OK;
+  if (!tiles || !out_offset || !out_stride || !d_sums)
+    return fail(RT_ERR_INVALID_ARGUMENT, "NULL tile table or output");
+  std::vector<rt::TileDev> td;
+  uint64_t out_pixels = 0;
+  if (int rc = tile_table(frame, tiles, out_offset, out_stride, n_tiles, &td, &out_pixels)) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  return render_tiles_device(scene, frame, td, out_pixels, 0, d_sums, s, sample_begin, true);
+}
+
+int rt_resolve_device_async(const float* d_sums, uint64_t n_pixels, uint32_t samples_per_pixel,
+                            float* d_rgb, void* stream) {
+  if (int rc = check_ready()) return rc;
+  if (n_pixels == 0) return RT_OK;
+  if (!d_sums || !d_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "NULL buffer");
+  if (samples_per_pixel == 0) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel is 0");
+  rt::ResolveParams rp;
+  rp.sums = d_sums;
+  rp.out = d_rgb;
+  rp.n_pixels = n_pixels;
+  rp.inv_spp = 1.0f / (float)samples_per_pixel;   // `1.0 / spp as f32`, src/cpu/mod.rs:67
+  RT_HIP(rt::launch_resolve(rp, stream ? (hipStream_t)stream : g.stream));
+  return RT_OK;
 }
 
 int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame, uint32_t row_begin,

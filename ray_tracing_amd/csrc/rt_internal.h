@@ -84,6 +84,8 @@ struct TraceParams {
   const TileDev* tiles;     // otherwise
   float* out;               // final buffer (slices == 1) or partial-sum buffer
   int resolve;              // apply x*(1/spp), sqrt, clamp on the way out (slices == 1 only)
+  int accumulate;           // slices == 1 only: an item's running sum starts from what `out`
+                            // already holds instead of zero (progressive rendering)
   float inv_spp;
   Counters* counters;
 };
@@ -98,6 +100,15 @@ struct ReduceParams {
   TileDev tile0;
   const TileDev* tiles;
   int resolve;
+  int accumulate;         // out = out + (sum of the planes) instead of out = sum of the planes
+  float inv_spp;
+};
+
+// compose_final_framebuffer's arithmetic over a buffer of sums (progressive rendering).
+struct ResolveParams {
+  const float* sums;      // [n_pixels][3]
+  float* out;             // [n_pixels][3]; may alias sums
+  uint64_t n_pixels;
   float inv_spp;
 };
 
@@ -114,6 +125,7 @@ size_t trace_lds_bytes(uint32_t n_spheres);
 hipError_t trace_max_blocks_per_cu(bool strict, bool multi, size_t lds_bytes, int* out);
 hipError_t launch_trace(const TraceParams& p, bool strict, int blocks, hipStream_t stream);
 hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream);
+hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream);
 hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream);
 
 }  // namespace rt

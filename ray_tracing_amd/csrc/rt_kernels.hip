@@ -626,6 +626,12 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TracePa
   P.sample = p.slice_begin[sl];
   P.sample_end = p.slice_begin[sl + 1];
   P.ar = P.ag = P.ab = 0.0f;
+  if (p.accumulate) {
+    // progressive rendering with the whole pass in one item: carry on from the sum so far,
+    // `pixel_color += color` (src/cpu/job.rs:58) continuing where the last pass stopped
+    const float* o = p.out + 3ull * P.out_index;
+    P.ar = o[0]; P.ag = o[1]; P.ab = o[2];
+  }
   P.has_item = true;
 }
 
@@ -868,14 +874,26 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
       const float* pl = src + 3ull * k * p.out_pixels;
       r += pl[0]; gch += pl[1]; b += pl[2];
     }
+    float* dst = p.out + 3ull * o;
+    if (p.accumulate) {
+      r = dst[0] + r; gch = dst[1] + gch; b = dst[2] + b;
+    }
     if (p.resolve) {
       r = resolve_channel(r, p.inv_spp);
       gch = resolve_channel(gch, p.inv_spp);
       b = resolve_channel(b, p.inv_spp);
     }
-    float* dst = p.out + 3ull * o;
     dst[0] = r; dst[1] = gch; dst[2] = b;
   }
+}
+
+// compose_final_framebuffer's per-channel arithmetic (src/cpu/mod.rs:67-75) over a buffer of
+// sums that several passes accumulated.
+__global__ __launch_bounds__(256) void resolve_kernel(const ResolveParams p) {
+  const uint64_t n = p.n_pixels * 3;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    p.out[i] = resolve_channel(p.sums[i], p.inv_spp);
 }
 
 // Per-ray test hook: one World::hit and one scatter decision per input ray, through the same
@@ -994,6 +1012,14 @@ hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream) {
   if (blocks > 8192) blocks = 8192;
   if (blocks == 0) return hipSuccess;
   hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream) {
+  uint64_t blocks = (p.n_pixels * 3 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@ EXPORTS = (
     "rt_render", "rt_render_tiles", "rt_compose",
     "rt_scene_create", "rt_scene_destroy",
     "rt_render_device_async", "rt_render_rows_device_async",
+    "rt_accumulate_device_async", "rt_resolve_device_async",
     "rt_synchronize", "rt_get_stats", "rt_get_launch_ms", "rt_get_phase_cycles", "rt_trace_rays",
 )
 
@@ -80,6 +81,8 @@ def lib():
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_render_device_async.argtypes = [vp, C.POINTER(abi.RtFrame), vp, vp, vp, u32, i, vp, vp]
     L.rt_render_rows_device_async.argtypes = [vp, C.POINTER(abi.RtFrame), u32, u32, i, vp, vp]
+    L.rt_accumulate_device_async.argtypes = [vp, C.POINTER(abi.RtFrame), u32, vp, vp, vp, u32, vp, vp]
+    L.rt_resolve_device_async.argtypes = [vp, u64, u32, vp, vp]
     L.rt_synchronize.argtypes = [vp]
     L.rt_get_stats.argtypes = [C.POINTER(abi.RtStats)]
     L.rt_get_launch_ms.argtypes = [u32, vp]
@@ -198,6 +201,25 @@ def render_device_async(scene, frame, tiles, out_offset, out_stride, resolve, d_
     check(lib().rt_render_device_async(scene.handle, C.byref(frame), abi.ptr(tiles), abi.ptr(off),
                                        abi.ptr(stride), len(tiles), int(bool(resolve)),
                                        C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr or 0)))
+
+
+def accumulate_device_async(scene, frame, sample_begin, tiles, out_offset, out_stride, d_sums_ptr,
+                            stream_ptr=None):
+    """rt_accumulate_device_async: adds samples [sample_begin, sample_begin + frame.spp) to the
+    un-normalised sums at d_sums_ptr."""
+    tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
+    off = np.ascontiguousarray(out_offset, dtype=np.uint64)
+    stride = np.ascontiguousarray(out_stride, dtype=np.uint32)
+    assert len(off) == len(tiles) == len(stride)
+    check(lib().rt_accumulate_device_async(scene.handle, C.byref(frame), int(sample_begin),
+                                           abi.ptr(tiles), abi.ptr(off), abi.ptr(stride),
+                                           len(tiles), C.c_void_p(d_sums_ptr),
+                                           C.c_void_p(stream_ptr or 0)))
+
+
+def resolve_device_async(d_sums_ptr, n_pixels, spp, d_rgb_ptr, stream_ptr=None):
+    check(lib().rt_resolve_device_async(C.c_void_p(d_sums_ptr), int(n_pixels), int(spp),
+                                        C.c_void_p(d_rgb_ptr), C.c_void_p(stream_ptr or 0)))
 
 
 def synchronize(stream_ptr=None):

@@ -189,3 +189,53 @@ def dispatch_work_gpu(dispatch, num_gpus=1, seed=1, flags=0):
                                        len(d.world.materials), int(seed) & 0xFFFFFFFF, int(flags),
                                        abi.ptr(out)))
     return out
+
+
+def dispatch_work_gpu_progressive(dispatch, passes, seed=1, flags=0, time_budget_s=None,
+                                  on_pass=None):
+    """The dispatch_work_* contract rendered in several passes that add into one buffer of
+    un-normalised sums (the additive JobResult.pixel_colors of src/cpu/job.rs:48-61, divided by
+    the sample count only at the end, src/cpu/mod.rs:67).
+
+    `passes` lists the samples per pixel of each pass; `dispatch.samples_per_pixel` is ignored in
+    favour of what was actually rendered.  With `time_budget_s` the passes stop early once that
+    much wall time has gone by (at least one pass always runs).  `on_pass(done_spp, sums)` is
+    called after each pass with the device tensor of sums (for previews or checkpoints).
+    Returns (framebuffer (H, W, 3) resolved with the rendered sample count, rendered spp).
+    With abi.RT_FLAG_SEQUENTIAL_SUM in `flags` the result is bit-identical to a one-pass render
+    of the same number of samples."""
+    import time
+
+    import torch
+
+    from . import hip
+
+    d = dispatch
+    W, H = d.image_width, d.image_height
+    device = torch.device("cuda", torch.cuda.current_device())
+    scene = hip.Scene(d.world.spheres, d.world.materials)
+    sums = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    tile = np.array([(0, 0, W, H)], dtype=abi.TILE_DTYPE)
+    off, stride = np.zeros(1, dtype=np.uint64), np.full(1, W, dtype=np.uint32)
+    done, t0 = 0, time.perf_counter()
+    for n in passes:
+        n = int(n)
+        if n <= 0:
+            continue
+        frame = hip.make_frame(d.camera.m, W, H, n, d.max_depth, seed, flags)
+        hip.accumulate_device_async(scene, frame, done, tile, off, stride, sums.data_ptr(), stream)
+        done += n
+        if on_pass is not None or time_budget_s is not None:
+            torch.cuda.synchronize()
+        if on_pass is not None:
+            on_pass(done, sums)
+        if time_budget_s is not None and time.perf_counter() - t0 >= time_budget_s:
+            break
+    if done == 0:
+        raise ValueError("no samples rendered: `passes` is empty")
+    rgb = torch.empty_like(sums)
+    hip.resolve_device_async(sums.data_ptr(), W * H, done, rgb.data_ptr(), stream)
+    torch.cuda.synchronize()
+    scene.close()
+    return rgb.cpu().numpy(), done

@@ -128,3 +128,60 @@ def dispatch_work_gpu_sharded(dispatch, seed=1, flags=0):
     torch.cuda.synchronize()
     scene.close()
     return fb.cpu().numpy() if fb is not None else None
+
+
+def sample_ranges(samples_per_pixel, world_size):
+    """[begin, end) of the samples each rank renders when a frame's SAMPLES are split."""
+    spp, n = int(samples_per_pixel), int(world_size)
+    return [((r * spp) // n, ((r + 1) * spp) // n) for r in range(n)]
+
+
+def dispatch_work_gpu_sample_split(dispatch, seed=1, flags=0, accumulate_fn=None, device=None):
+    """Alternative sharding for images too small to split by rows: every rank renders the WHOLE
+    frame for its share of the samples (rt_accumulate_device_async on a zeroed buffer), the
+    un-normalised sums are gathered to rank 0 and added there in rank order, then resolved.
+    The exchange moves world_size full frames, so row sharding is the default; this one exists
+    because sums are additive (src/cpu/job.rs:48-61).  The result depends on the number of ranks
+    only through the association of the per-rank sums.
+
+    `accumulate_fn(sample_begin, n_samples, sums_tensor)` is injectable for CPU tests."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    d = dispatch
+    W, H = d.image_width, d.image_height
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    begin, end = sample_ranges(d.samples_per_pixel, world)[rank]
+    sums = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
+    scene = None
+    if accumulate_fn is None:
+        from . import hip
+        scene = hip.Scene(d.world.spheres, d.world.materials)
+        stream = torch.cuda.current_stream().cuda_stream
+        tile = np.array([(0, 0, W, H)], dtype=abi.TILE_DTYPE)
+        off, stride = np.zeros(1, dtype=np.uint64), np.full(1, W, dtype=np.uint32)
+
+        def accumulate_fn(b, n, t):
+            frame = hip.make_frame(d.camera.m, W, H, n, d.max_depth, seed, flags)
+            hip.accumulate_device_async(scene, frame, b, tile, off, stride, t.data_ptr(), stream)
+
+    if end > begin:
+        accumulate_fn(begin, end - begin, sums)
+    gathered = [torch.zeros_like(sums) for _ in range(world)] if rank == 0 else None
+    dist.gather(sums, gathered, dst=0)
+    out = None
+    if rank == 0:
+        total = gathered[0]
+        for r in range(1, world):
+            total = total + gathered[r]
+        x = torch.sqrt(total * (1.0 / float(d.samples_per_pixel)))
+        # Rust's f32::clamp: NaN stays NaN (src/cpu/mod.rs:73-75)
+        x = torch.where(x < 0.0, torch.zeros_like(x), torch.where(x > 0.999, torch.full_like(x, 0.999), x))
+        out = x.cpu().numpy()
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    if scene is not None:
+        scene.close()
+    return out

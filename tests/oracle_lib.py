@@ -123,6 +123,8 @@ def lib():
     L.ro_shoot_ray_iter.restype = Vec3
     L.ro_bounce.argtypes = [C.POINTER(World), C.POINTER(Ray), C.POINTER(Rng), C.c_int, vp]
     L.ro_execute_job.argtypes = [vp, C.POINTER(JobData), vp, C.POINTER(Counters)]
+    L.ro_accumulate_job.argtypes = [vp, C.POINTER(JobData), C.c_uint32, C.c_uint32, vp,
+                                    C.POINTER(Counters)]
     L.ro_create_job_queue.argtypes = [u32, u32, u32, u32, vp, u32]
     L.ro_create_job_queue.restype = u32
     L.ro_debug_write_job_queue_to_framebuffer.argtypes = [u32, u32, vp, u32, vp]
@@ -234,6 +236,26 @@ def bounce(world, rays_in, seed, pow5_mode=RO_POW5_MUL):
         L.ro_bounce(C.byref(world), C.byref(rr), C.byref(rng), pow5_mode,
                     C.c_void_p(out[i:i + 1].ctypes.data))
     return out
+
+
+def accumulate_tiles(spheres, materials, camera, width, height, max_depth, seed, tiles,
+                     sample_begin, n_samples, sums, mode=RO_MODE_ITER_MUL):
+    """ro_accumulate_job over `tiles`: adds samples [sample_begin, sample_begin + n_samples) to
+    the concatenated per-tile sums `sums` (shape (sum w*h, 3)), in place."""
+    L = lib()
+    world = make_world(spheres, materials)
+    tiles = np.ascontiguousarray(tiles, dtype=abi.TILE_DTYPE)
+    data = JobData(width, height, max_depth, n_samples, seed, mode, C.pointer(camera),
+                   C.pointer(world))
+    ctr = Counters(0, 0)
+    off = 0
+    for t in tiles:
+        n = int(t["width"]) * int(t["height"])
+        L.ro_accumulate_job(C.c_void_p(np.asarray(t).ctypes.data), C.byref(data),
+                            int(sample_begin), int(n_samples),
+                            C.c_void_p(sums[off:off + n].ctypes.data), C.byref(ctr))
+        off += n
+    return ctr
 
 
 def render(spheres, materials, camera, width, height, spp, max_depth, seed,

@@ -80,3 +80,61 @@ def test_row_plan_covers_every_row_once():
             # balance: no rank has more than one block more than another
             rows = [plan.rows_of(r) for r in range(world)]
             assert max(rows) - min(rows) <= plan.block_rows
+
+
+def _sample_split_worker(rank, world, port, out_path):
+    """Every rank renders the whole (tiny) frame for its share of the samples - here with the
+    CPU oracle standing in for the kernel - and rank 0 adds the gathered sums in rank order."""
+    import torch
+    import torch.distributed as dist
+    import oracle_lib as O
+    from ray_tracing_amd import host
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank,
+                            world_size=world)
+    w, h, spp, depth, seed = 20, 12, 7, 50, 5
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
+    scene = host.create_random_world(1, (-4, 4))
+    d = host.Dispatch.new(host.create_job_queue(w, h, 64, 64), w, h, depth, spp, camera, scene)
+    tile = np.array([(0, 0, w, h)], dtype=multi_gpu.abi.TILE_DTYPE)
+
+    def accumulate_fn(begin, n, sums):
+        flat = sums.view(-1, 3).numpy()
+        O.accumulate_tiles(scene.spheres, scene.materials, camera.m, w, h, depth, seed, tile,
+                           begin, n, flat)
+
+    fb = multi_gpu.dispatch_work_gpu_sample_split(d, seed=seed, accumulate_fn=accumulate_fn,
+                                                  device=torch.device("cpu"))
+    if rank == 0:
+        np.save(out_path, fb)
+    else:
+        assert fb is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_samples_are_split_gathered_and_added_in_rank_order(tmp_path, world):
+    import torch.multiprocessing as mp
+    import oracle_lib as O
+    from ray_tracing_amd import host
+    assert multi_gpu.sample_ranges(7, 3) == [(0, 2), (2, 4), (4, 7)]
+    assert multi_gpu.sample_ranges(2, 4) == [(0, 0), (0, 1), (1, 1), (1, 2)]
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_sample_split_worker, args=(world, free_port(), out), nprocs=world, join=True)
+    fb = np.load(out)
+    w, h, spp, depth, seed = 20, 12, 7, 50, 5
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
+    scene = host.create_random_world(1, (-4, 4))
+    tile = np.array([(0, 0, w, h)], dtype=multi_gpu.abi.TILE_DTYPE)
+    total = None
+    for begin, end in multi_gpu.sample_ranges(spp, world):
+        part = np.zeros((w * h, 3), dtype=np.float32)
+        O.accumulate_tiles(scene.spheres, scene.materials, camera.m, w, h, depth, seed, tile,
+                           begin, end - begin, part)
+        total = part if total is None else total + part
+    with np.errstate(invalid="ignore"):
+        expect = np.sqrt(total * np.float32(1.0 / spp)).reshape(h, w, 3)
+    expect = np.where(expect > np.float32(0.999), np.float32(0.999), expect)
+    ok = ~np.isnan(expect)
+    assert np.array_equal(np.isnan(expect), np.isnan(fb))
+    assert np.allclose(fb[ok], expect[ok], rtol=0, atol=1e-7)
