@@ -76,6 +76,15 @@ typedef struct rt_tile {
                                      per-pixel sum is then formed in sample order, exactly like
                                      `pixel_color += color` in src/cpu/job.rs:58 */
 
+#define RT_FLAG_ACCEL 4u          /* World::hit (src/main.rs:175-189) through a bounding-volume
+                                     hierarchy instead of the linear scan over every sphere.
+                                     Opt-in: the work no longer grows with the sphere count, so
+                                     a roofline counted in ray/sphere tests does not apply to it.
+                                     Every sphere the traversal reaches goes through the same
+                                     exact arithmetic and tie rule, and its boxes are widened by
+                                     a bound on the reference's own rounding, so the result is
+                                     bit-identical to the scan's */
+
 /* Mirror of `struct Dispatch` (reference src/cpu/mod.rs:19-30) plus the render seed.
  * `tiles` may be NULL for rt_render() (the GPU path does not need the caller's tiling);
  * rt_render_tiles() requires it. */

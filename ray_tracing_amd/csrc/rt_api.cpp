@@ -23,6 +23,10 @@ struct rt_scene {
   void* geom = nullptr;
   void* aux = nullptr;
   void* mat = nullptr;
+  void* bvh = nullptr;          // RT_FLAG_ACCEL: nodes, permuted geometry, original indices
+  void* leaf_geom = nullptr;
+  void* leaf_index = nullptr;
+  uint32_t bvh_depth = 0;
   int device = -1;
 };
 
@@ -139,7 +143,7 @@ int check_frame(const rt_frame* f) {
   if (f->samples_per_pixel == 0) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel is 0");
   if ((uint64_t)f->image_width * f->image_height > 0x7FFFFFFFull)
     return fail(RT_ERR_LIMIT, "more than 2^31 pixels");
-  if (f->flags & ~(RT_FLAG_STRICT_FP | RT_FLAG_SEQUENTIAL_SUM))
+  if (f->flags & ~(RT_FLAG_STRICT_FP | RT_FLAG_SEQUENTIAL_SUM | RT_FLAG_ACCEL))
     return fail(RT_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", f->flags);
   return RT_OK;
 }
@@ -245,6 +249,10 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   p.counters = slot->counters;
 
   const bool strict = (frame->flags & RT_FLAG_STRICT_FP) != 0;
+  const bool accel = (frame->flags & RT_FLAG_ACCEL) != 0;
+  if (accel && scene->bvh_depth > rt::bvh_stack_depth())
+    return fail(RT_ERR_LIMIT, "hierarchy of %u levels exceeds the traversal stack (%u)",
+                scene->bvh_depth, rt::bvh_stack_depth());
 
   if (frame->max_depth == 0) {
     // shoot_ray(ray, 0) is black (src/main.rs:192-194): every sum is 0 and nothing is traced
@@ -299,10 +307,10 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   }
   p.out = trace_out;
 
-  const size_t lds = rt::trace_lds_bytes(scene->dev.n_spheres);
+  const size_t lds = rt::trace_lds_bytes(scene->dev.n_spheres, accel);
   const bool multi = scene->dev.n_spheres > rt::kChunkSpheres;
   int per_cu = 0;
-  RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, lds, &per_cu));
+  RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, accel, lds, &per_cu));
   if (per_cu < 1) return fail(RT_ERR_DEVICE, "trace kernel does not fit on a CU (LDS %zu B)", lds);
   int blocks = per_cu * g.cus;
   const uint64_t lanes_needed = ((uint64_t)p.total_items + rt::kRaysPerLane - 1) / rt::kRaysPerLane;
@@ -313,7 +321,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   RT_HIP(hipMemsetAsync(slot->counters, 0, sizeof(rt::Counters), stream));
   const int ev = (int)(g.launches % kEventRing);
   RT_HIP(hipEventRecord(g.ev_begin[ev], stream));
-  RT_HIP(rt::launch_trace(p, strict, blocks, stream));
+  RT_HIP(rt::launch_trace(p, strict, accel, blocks, stream));
   RT_HIP(hipEventRecord(g.ev_end[ev], stream));
   g.launches++;
   slot->event = ev;
@@ -339,7 +347,8 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   slot->last.slices = p.slices;
   slot->last.workgroups = (uint32_t)blocks;
   slot->last.threads_per_workgroup = rt::kThreads;
-  slot->last.sphere_tests = scene->dev.n_spheres;   // multiplied by rays in rt_get_stats
+  // multiplied by rays in rt_get_stats; a traversal does not count its tests
+  slot->last.sphere_tests = accel ? 0 : scene->dev.n_spheres;
   return RT_OK;
 }
 
@@ -497,6 +506,29 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
   s->dev.mat = (const float4*)s->mat;
   s->dev.n_spheres = n_spheres;
   s->dev.n_materials = n_materials;
+
+  // the optional hierarchy (RT_FLAG_ACCEL)
+  rt::BvhHost bvh;
+  rt::build_bvh(spheres, n_spheres, &bvh);
+  s->bvh_depth = bvh.depth;
+  s->dev.bvh_info = bvh.info;
+  const size_t nn = bvh.nodes.empty() ? 1 : bvh.nodes.size();
+  const size_t nl = bvh.leaf_geom.empty() ? 1 : bvh.leaf_geom.size();
+  RT_HIP(hipMalloc(&s->bvh, nn * sizeof(rt::BvhNode)));
+  RT_HIP(hipMalloc(&s->leaf_geom, nl * sizeof(float4)));
+  RT_HIP(hipMalloc(&s->leaf_index, nl * sizeof(uint32_t)));
+  if (!bvh.nodes.empty())
+    RT_HIP(hipMemcpy(s->bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rt::BvhNode),
+                     hipMemcpyHostToDevice));
+  if (!bvh.leaf_geom.empty()) {
+    RT_HIP(hipMemcpy(s->leaf_geom, bvh.leaf_geom.data(), bvh.leaf_geom.size() * sizeof(float4),
+                     hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(s->leaf_index, bvh.leaf_index.data(),
+                     bvh.leaf_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  s->dev.bvh = (const rt::BvhNode*)s->bvh;
+  s->dev.leaf_geom = (const float4*)s->leaf_geom;
+  s->dev.leaf_index = (const uint32_t*)s->leaf_index;
   guard.s = nullptr;
   *out_scene = s;
   return RT_OK;
@@ -508,6 +540,9 @@ int rt_scene_destroy(rt_scene* scene) {
   if (scene->geom) (void)hipFree(scene->geom);
   if (scene->aux) (void)hipFree(scene->aux);
   if (scene->mat) (void)hipFree(scene->mat);
+  if (scene->bvh) (void)hipFree(scene->bvh);
+  if (scene->leaf_geom) (void)hipFree(scene->leaf_geom);
+  if (scene->leaf_index) (void)hipFree(scene->leaf_index);
   delete scene;
   return RT_OK;
 }
@@ -766,6 +801,10 @@ int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays,
   hp.out = (rt_ray_out*)dout.p;
   hp.n_rays = n_rays;
   hp.seed = seed;
+  hp.accel = (flags & RT_FLAG_ACCEL) != 0 ? 1 : 0;
+  if (hp.accel && scene->bvh_depth > rt::bvh_stack_depth())
+    return fail(RT_ERR_LIMIT, "hierarchy of %u levels exceeds the traversal stack (%u)",
+                scene->bvh_depth, rt::bvh_stack_depth());
   RT_HIP(rt::launch_hook(hp, (flags & RT_FLAG_STRICT_FP) != 0, g.stream));
   RT_HIP(hipStreamSynchronize(g.stream));
   RT_HIP(hipMemcpy(out, dout.p, (size_t)n_rays * sizeof(rt_ray_out), hipMemcpyDeviceToHost));

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/rt_abi.h"
 
 namespace rt {
@@ -46,6 +48,30 @@ struct TileDev {
 //   geom[i] = (cx, cy, cz, radius*radius)       read when a sphere is replayed exactly
 //   aux[i]  = (radius, material_id bits)        read once per hit
 //   mat[2m] = (r, g, b, flags bits), mat[2m+1] = (metallic_strength, ir, 0, 0)
+// Optional bounding-volume hierarchy (RT_FLAG_ACCEL; built by build_bvh in rt_bvh.cpp).
+constexpr uint32_t kBvhLeaf = 0x80000000u;
+struct BvhNode {
+  float lo[3];
+  uint32_t a;    // interior: left child; leaf: first slot in leaf_geom / leaf_index
+  float hi[3];
+  uint32_t b;    // interior: right child; leaf: kBvhLeaf | number of spheres
+};
+struct BvhInfo {
+  uint32_t n_big = 0;      // leaf slots [0, n_big) hold the spheres kept out of the tree
+  uint32_t n_nodes = 0;    // 0: the tree is empty (every sphere is "big", or there is none)
+  float centre[3] = {0, 0, 0};   // a ball (centre, extent) holds every tree sphere's centre
+  float extent = 0;
+  float r_min = 0, r_max = 0;    // smallest / largest radius among the tree's spheres
+};
+struct BvhHost {
+  std::vector<BvhNode> nodes;
+  std::vector<float4> leaf_geom;     // (cx, cy, cz, r*r), big spheres first, then tree order
+  std::vector<uint32_t> leaf_index;  // original sphere number of each slot
+  uint32_t depth = 0;                // levels of the tree (the traversal stack must hold them)
+  BvhInfo info;
+};
+void build_bvh(const rt_sphere* spheres, uint32_t n, BvhHost* out);
+
 struct SceneDev {
   const float4* trig;
   const float4* geom;
@@ -53,6 +79,11 @@ struct SceneDev {
   const float4* mat;
   uint32_t n_spheres;
   uint32_t n_materials;
+  // RT_FLAG_ACCEL
+  const BvhNode* bvh;
+  const float4* leaf_geom;
+  const uint32_t* leaf_index;
+  BvhInfo bvh_info;
 };
 
 struct Counters {
@@ -118,12 +149,15 @@ struct HookParams {
   rt_ray_out* out;
   uint32_t n_rays;
   uint32_t seed;
+  int accel;              // World::hit through the hierarchy instead of the scan
 };
 
 // Launchers implemented in rt_kernels.hip.  `strict` selects the non-contracted discriminant.
-size_t trace_lds_bytes(uint32_t n_spheres);
-hipError_t trace_max_blocks_per_cu(bool strict, bool multi, size_t lds_bytes, int* out);
-hipError_t launch_trace(const TraceParams& p, bool strict, int blocks, hipStream_t stream);
+size_t trace_lds_bytes(uint32_t n_spheres, bool accel);
+uint32_t bvh_stack_depth();
+hipError_t trace_max_blocks_per_cu(bool strict, bool multi, bool accel, size_t lds_bytes, int* out);
+hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, int blocks,
+                        hipStream_t stream);
 hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream);
 hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream);

@@ -552,6 +552,117 @@ __device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, uint3
   }
 }
 
+// ---- World::hit through the optional bounding-volume hierarchy (RT_FLAG_ACCEL) ----------------
+// Every sphere the traversal reaches goes through candidate_hit, i.e. the reference's exact
+// Sphere::hit arithmetic and World::hit's minimum-t / later-sphere-wins rule, which does not
+// depend on the visiting order.  So the result is the linear scan's, bit for bit, as long as no
+// sphere is pruned that the reference's arithmetic would accept.  A sphere (c, r) is accepted
+// only if its COMPUTED discriminant is >= 0 and its computed root lies in [t_min, closest].
+// With u = 2^-24 and S = |o-c|^2 + r^2 the computed discriminant is within 22u |d|^2 S of the
+// exact one, so the ray's line passes within r + 11u S / r of c; and the computed root is within
+// sqrt(22u S) + 8u |o-c| (as a distance) of a point of that widened sphere.  A box that holds
+// the sphere, widened by the sum of the two, therefore holds the computed hit point, and a slab
+// test against it (with a relative 1e-5 on its own rounding) brackets the computed root.  The
+// margin below is twice that sum, with |o-c| bounded by the distance to the ball that holds all
+// centres and r by the tree's smallest and largest radius.
+constexpr int kBvhStack = 24;   // balanced median splits: depth <= log2(n) <= 24
+
+struct BvhRay {
+  V3 o, d, inv;
+  float a, margin;
+};
+
+__device__ __forceinline__ float bvh_margin(const BvhInfo& bi, V3 o) {
+  const float u = 5.9604644775390625e-8f;   // 2^-24
+  const V3 oc = sub(o, mk(bi.centre[0], bi.centre[1], bi.centre[2]));
+  const float dist = __builtin_sqrtf(dot(oc, oc)) * 1.000001f + bi.extent;
+  const float S = dist * dist + bi.r_max * bi.r_max;
+  return 2.0f * (11.0f * u * S / bi.r_min + __builtin_sqrtf(22.0f * u * S) + 8.0f * u * dist);
+}
+
+// Does the ray reach the widened box within [t_min, closest]?  *t_near is its entry parameter.
+__device__ __forceinline__ bool bvh_box(const BvhRay& r, const float4 lo, const float4 hi,
+                                        float closest, float* t_near) {
+  const float ax = (lo.x - r.margin - r.o.x) * r.inv.x, bx = (hi.x + r.margin - r.o.x) * r.inv.x;
+  const float ay = (lo.y - r.margin - r.o.y) * r.inv.y, by = (hi.y + r.margin - r.o.y) * r.inv.y;
+  const float az = (lo.z - r.margin - r.o.z) * r.inv.z, bz = (hi.z + r.margin - r.o.z) * r.inv.z;
+  // fminf/fmaxf drop a NaN operand (0 * inf when the origin sits on a slab of an axis-parallel
+  // ray), which only removes a constraint
+  float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                             __builtin_fminf(az, bz));
+  float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                             __builtin_fmaxf(az, bz));
+  tn = tn - 1e-5f * __builtin_fabsf(tn);
+  tf = tf + 1e-5f * __builtin_fabsf(tf);
+  *t_near = tn;
+  // written so that a NaN (nothing constrains the ray) visits the box
+  return !(tf < tn) && !(tf < kTMin * 0.999f) && !(tn > closest);
+}
+
+// `stack` is this thread's column of a [kBvhStack][kThreads] LDS array.
+__device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, uint32_t* stack) {
+  if (!P.alive) return;
+  const V3 o = mk(P.ox, P.oy, P.oz), d = mk(P.dx, P.dy, P.dz);
+  float closest = kTMax;
+  uint32_t best = kNone;
+  if (__builtin_expect(P.degenerate, 0)) {
+    // zero or non-finite ray: World::hit's loop as written, first sphere to last
+    for (uint32_t i = 0; i < sc.n_spheres; ++i)
+      exact_hit(sc.geom[i], i, o, d, P.a, closest, best);
+    P.closest = closest;
+    P.best = best;
+    return;
+  }
+  ReplayBounds rb = replay_bounds(closest, P.a);
+  const BvhInfo& bi = sc.bvh_info;
+  for (uint32_t k = 0; k < bi.n_big; ++k)
+    candidate_hit(sc.leaf_geom[k], sc.leaf_index[k], o, d, P.a, rb, closest, best);
+  if (bi.n_nodes != 0) {
+    BvhRay r;
+    r.o = o;
+    r.d = d;
+    r.a = P.a;
+    r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.margin = bvh_margin(bi, o);
+    const float4* nodes = reinterpret_cast<const float4*>(sc.bvh);
+    int sp = 0;
+    uint32_t node = 0;
+    for (;;) {
+      const float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
+      const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
+      bool pop = true;
+      if (b & kBvhLeaf) {
+        const uint32_t count = b & ~kBvhLeaf;
+        for (uint32_t k = 0; k < count; ++k)
+          candidate_hit(sc.leaf_geom[a + k], sc.leaf_index[a + k], o, d, P.a, rb, closest, best);
+      } else {
+        const float4 l0 = nodes[2 * a], l1 = nodes[2 * a + 1];
+        const float4 r0 = nodes[2 * b], r1 = nodes[2 * b + 1];
+        float tl, tr;
+        const bool hl = bvh_box(r, l0, l1, closest, &tl);
+        const bool hr = bvh_box(r, r0, r1, closest, &tr);
+        if (hl && hr) {
+          const bool left_first = !(tr < tl);
+          stack[sp * kThreads] = left_first ? b : a;
+          sp++;
+          node = left_first ? a : b;
+          pop = false;
+        } else if (hl || hr) {
+          node = hl ? a : b;
+          pop = false;
+        }
+      }
+      if (pop) {
+        if (sp == 0) break;
+        sp--;
+        node = stack[sp * kThreads];
+      }
+    }
+  }
+  P.closest = closest;
+  P.best = best;
+}
+
 // Reserve work for the lanes of this wave whose `need` is set.  Returns the lane's item or
 // kNone once the frame's items are exhausted.  Must be called by all 64 lanes.
 __device__ __forceinline__ uint32_t wave_fetch(bool need, uint32_t& next, uint32_t& end,
@@ -682,7 +793,7 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
   return s;
 }
 
-template <bool STRICT, bool MULTI>
+template <bool STRICT, bool MULTI, bool ACCEL = false>
 __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const TraceParams p) {
   extern __shared__ float4 lds[];
   const uint32_t n = p.scene.n_spheres;
@@ -694,10 +805,12 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
   const uint32_t wave = threadIdx.x / kWave;
   uint16_t* q = qall + wave * (R * Q * kWave);
 
-  if (!MULTI) {
+  if (!MULTI && !ACCEL) {
     stage_chunk(p.scene, 0, n, sph, sr2);
     __syncthreads();
   }
+  // ACCEL: the LDS holds the traversal stacks instead, one column per thread
+  uint32_t* bvh_stack = reinterpret_cast<uint32_t*>(lds) + threadIdx.x;
 
   Path P[R];
 #pragma unroll
@@ -764,7 +877,7 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
 #ifdef RT_DIAG_PHASES
     if (exhausted && clk.t_exhausted == 0) clk.t_exhausted = __builtin_amdgcn_s_memtime();
 #endif
-    if (exhausted) {
+    if (!ACCEL && exhausted) {
       uint32_t live = 0;
       bool odd = false;
 #pragma unroll
@@ -774,7 +887,10 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
       }
       tail = live <= kTailPaths && __builtin_amdgcn_ballot_w64(odd) == 0;
     }
-    if (MULTI) {
+    if (ACCEL) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) bvh_hit(P[r], p.scene, bvh_stack);
+    } else if (MULTI) {
       for (uint32_t base = 0; base < n; base += kChunkSpheres) {
         const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
         __syncthreads();   // every wave is done with the previous chunk
@@ -932,13 +1048,17 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     P[0].alive = true;
   }
   const uint32_t n = p.scene.n_spheres;
-  for (uint32_t base = 0; base < n; base += kChunkSpheres) {
-    const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
-    __syncthreads();
-    stage_chunk(p.scene, base, cn, sph, sr2);
-    __syncthreads();
-    PhaseClock clk = {};
-    scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
+  if (p.accel) {
+    bvh_hit(P[0], p.scene, reinterpret_cast<uint32_t*>(lds) + threadIdx.x);
+  } else {
+    for (uint32_t base = 0; base < n; base += kChunkSpheres) {
+      const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
+      __syncthreads();
+      stage_chunk(p.scene, base, cn, sph, sr2);
+      __syncthreads();
+      PhaseClock clk = {};
+      scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
+    }
   }
   if (!live) return;
 
@@ -979,25 +1099,34 @@ constexpr size_t kQueueBytes = (size_t)kWavesPerWg * R * Q * kWave * sizeof(uint
 
 }  // namespace
 
-size_t trace_lds_bytes(uint32_t n_spheres) {
+size_t trace_lds_bytes(uint32_t n_spheres, bool accel) {
+  if (accel) return (size_t)kBvhStack * kThreads * sizeof(uint32_t);
   return (size_t)lds_capacity(n_spheres) * (sizeof(float4) + sizeof(float)) + kQueueBytes;
 }
+
+uint32_t bvh_stack_depth() { return kBvhStack; }
 
 template <bool STRICT, bool MULTI>
 static hipError_t occupancy(size_t lds, int* out) {
   return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, trace_kernel<STRICT, MULTI>, kThreads, lds);
 }
 
-hipError_t trace_max_blocks_per_cu(bool strict, bool multi, size_t lds, int* out) {
+hipError_t trace_max_blocks_per_cu(bool strict, bool multi, bool accel, size_t lds, int* out) {
+  if (accel)
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, trace_kernel<false, false, true>,
+                                                        kThreads, lds);
   if (strict) return multi ? occupancy<true, true>(lds, out) : occupancy<true, false>(lds, out);
   return multi ? occupancy<false, true>(lds, out) : occupancy<false, false>(lds, out);
 }
 
-hipError_t launch_trace(const TraceParams& p, bool strict, int blocks, hipStream_t stream) {
+hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, int blocks,
+                        hipStream_t stream) {
   const bool multi = p.scene.n_spheres > kChunkSpheres;
-  const size_t lds = trace_lds_bytes(p.scene.n_spheres);
+  const size_t lds = trace_lds_bytes(p.scene.n_spheres, accel);
   const dim3 grid(blocks), block(kThreads);
-  if (strict) {
+  if (accel) {
+    hipLaunchKernelGGL((trace_kernel<false, false, true>), grid, block, lds, stream, p);
+  } else if (strict) {
     if (multi) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, stream, p);
   } else {

@@ -1,0 +1,125 @@
+"""RT_FLAG_ACCEL: World::hit through the bounding-volume hierarchy must give the linear scan's
+bits - per ray and per image - because every sphere it reaches goes through the same exact
+arithmetic and tie rule, and it may never prune a sphere the reference's arithmetic accepts."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ray_tracing_amd import abi, hip
+
+pytestmark = pytest.mark.gpu
+
+SEQ = abi.RT_FLAG_SEQUENTIAL_SUM
+ACCEL = abi.RT_FLAG_ACCEL
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    hip.init(0)
+    yield
+
+
+def camera(aspect=16 / 9):
+    return O.camera_new((13, 2, 3), (0, 0, 0), 20.0, aspect)
+
+
+def rays_for(s, m, n_primary, seed):
+    """Camera rays, two generations of scattered rays, and rays from far outside the scene."""
+    cam = camera()
+    w = O.make_world(s, m)
+    rs = np.random.default_rng(seed)
+    L = O.lib()
+    rays = np.zeros(n_primary, dtype=abi.RAY_IN_DTYPE)
+    for i in range(n_primary):
+        u, v = rs.uniform(-1, 1, size=2)
+        r = L.ro_camera_get_ray(cam, float(u), float(v))
+        rays[i] = (*r.origin.tup(), *r.dir.tup())
+    gens = [rays]
+    for g in range(2):
+        out = O.bounce(w, gens[-1], seed + 100 + g)
+        sel = out[out["scattered"] == 1]
+        nxt = np.zeros(len(sel), dtype=abi.RAY_IN_DTYPE)
+        nxt["ox"], nxt["oy"], nxt["oz"] = sel["px"], sel["py"], sel["pz"]
+        nxt["dx"], nxt["dy"], nxt["dz"] = sel["sx"], sel["sy"], sel["sz"]
+        gens.append(nxt)
+    far = np.zeros(200, dtype=abi.RAY_IN_DTYPE)
+    org = rs.normal(size=(200, 3)) * 400.0
+    tgt = rs.uniform(-10, 10, size=(200, 3)) * [1, 0.05, 1]
+    far["ox"], far["oy"], far["oz"] = org.T
+    far["dx"], far["dy"], far["dz"] = ((tgt - org) * rs.uniform(0.01, 3.0, size=(200, 1))).T
+    odd = np.zeros(6, dtype=abi.RAY_IN_DTYPE)
+    odd[0] = (0, 1, 0, 0, 0, 0)                  # zero direction
+    odd[1] = (0, 1, 0, np.inf, 0, 0)             # infinite direction
+    odd[2] = (0, 1, 0, np.nan, 1, 0)             # NaN direction
+    odd[3] = (13, 2, 3, 1, 0, 0)                 # axis-parallel
+    odd[4] = (0, 0.2, 0, 0, 1, 0)                # axis-parallel from inside the cluster
+    odd[5] = (1e30, 0, 0, -1, 0, 0)              # origin beyond the scan's range
+    return np.concatenate(gens + [far, odd])
+
+
+def same_records(a, b):
+    for f in a.dtype.names:
+        x, y = a[f], b[f]
+        if x.dtype.kind == "f":
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), f
+        else:
+            assert np.array_equal(x, y), f
+
+
+@pytest.mark.parametrize("grid", [(-4, 4), (-11, 11), (-30, 30)])
+def test_per_ray_records_equal_the_scan(grid):
+    s, m = O.random_world(1, *grid)
+    scene = hip.Scene(s, m)
+    rays = rays_for(s, m, 1500, seed=5)
+    brute = hip.trace_rays(scene, rays, seed=9, flags=0)
+    accel = hip.trace_rays(scene, rays, seed=9, flags=ACCEL)
+    same_records(brute, accel)
+    assert brute["hit"].sum() > 500
+    scene.close()
+
+
+def test_per_ray_degenerate_scenes():
+    cam_rays = rays_for(*O.random_world(1, -4, 4), 300, seed=2)
+    s, m = O.random_world(1, -4, 4)
+    cases = []
+    cases.append((s[:0], m))                                  # empty world
+    cases.append((s[:1], m))                                  # one sphere
+    same = s[:64].copy()
+    same["radius"] = 0.2                                      # no "big" sphere at all
+    cases.append((same, m))
+    stacked = s[:40].copy()
+    stacked["x"], stacked["y"], stacked["z"] = 0.0, 0.2, 0.0  # forty coincident spheres
+    cases.append((stacked, m))
+    flat = s[:64].copy()
+    flat["radius"][::3] = 0.0                                 # zero radii
+    cases.append((flat, m))
+    for spheres, mats in cases:
+        scene = hip.Scene(spheres, mats)
+        same_records(hip.trace_rays(scene, cam_rays, seed=1, flags=0),
+                     hip.trace_rays(scene, cam_rays, seed=1, flags=ACCEL))
+        scene.close()
+
+
+@pytest.mark.parametrize("grid,w,h,spp", [((-4, 4), 96, 54, 6), ((-50, 50), 64, 36, 3)])
+def test_sequential_sums_equal_the_oracle(grid, w, h, spp):
+    s, m = O.random_world(1, *grid)
+    cam = camera(w / h)
+    tiles = O.job_queue(w, h, 64, 64)
+    _, _, ctr, ref = O.render(s, m, cam, w, h, spp, 50, 3, mode=O.RO_MODE_ITER_MUL, threads=16,
+                              tiles=tiles, want_sums=True)
+    got = hip.render_tiles(s, m, cam, w, h, spp, 50, 3, tiles, flags=SEQ | ACCEL)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    st = hip.get_stats()
+    assert st.rays == ctr.rays and st.samples == ctr.samples
+
+
+@pytest.mark.parametrize("glass", [False, True])
+def test_images_equal_the_scan(glass):
+    w, h, spp = 320, 180, 16
+    s, m = O.random_world(1, -11, 11, 0.1 if glass else 0.8, 0.2 if glass else 0.95, int(glass))
+    cam = camera(w / h)
+    a = hip.render(s, m, cam, w, h, spp, 50, 7, flags=0)
+    b = hip.render(s, m, cam, w, h, spp, 50, 7, flags=ACCEL)
+    both = ~(np.isnan(a) | np.isnan(b))
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.array_equal(a[both].view(np.uint32), b[both].view(np.uint32))
