@@ -307,13 +307,18 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   }
   p.out = trace_out;
 
-  const size_t lds = rt::trace_lds_bytes(scene->dev.n_spheres, accel);
+  bool bvh_in_lds = false;
+  p.bvh_stack = scene->bvh_depth ? scene->bvh_depth : 1;
+  const size_t lds = rt::trace_lds_bytes(scene->dev.n_spheres, accel, scene->dev.bvh_info.n_nodes,
+                                         p.bvh_stack, &bvh_in_lds);
+  p.bvh_in_lds = bvh_in_lds ? 1 : 0;
   const bool multi = scene->dev.n_spheres > rt::kChunkSpheres;
   int per_cu = 0;
   RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, accel, lds, &per_cu));
   if (per_cu < 1) return fail(RT_ERR_DEVICE, "trace kernel does not fit on a CU (LDS %zu B)", lds);
   int blocks = per_cu * g.cus;
-  const uint64_t lanes_needed = ((uint64_t)p.total_items + rt::kRaysPerLane - 1) / rt::kRaysPerLane;
+  const uint32_t paths_per_lane = accel ? 1 : rt::kRaysPerLane;
+  const uint64_t lanes_needed = ((uint64_t)p.total_items + paths_per_lane - 1) / paths_per_lane;
   const uint64_t blocks_needed = (lanes_needed + rt::kThreads - 1) / rt::kThreads;
   if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
   if (blocks < 1) blocks = 1;
@@ -343,7 +348,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   }
 
   slot->last = {};
-  slot->last.rays_per_lane = rt::kRaysPerLane;
+  slot->last.rays_per_lane = paths_per_lane;
   slot->last.slices = p.slices;
   slot->last.workgroups = (uint32_t)blocks;
   slot->last.threads_per_workgroup = rt::kThreads;

@@ -18,6 +18,7 @@ constexpr int kQueueSlots = 20;         // deferred-candidate slots per path (u1
 constexpr int kScanUnroll = 4;          // spheres per unrolled block of the scan
 constexpr uint32_t kChunkSpheres = 2016; // spheres resident in LDS at a time: with the read-ahead
                                          // padding and the queues, two workgroups fill a CU's LDS
+constexpr size_t kLdsPerWorkgroup = 160 * 1024 / 2;   // two workgroups share a CU's 160 KB
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic
 constexpr uint32_t kTargetItems = 1u << 20; // below this many pixels, split samples over lanes
@@ -115,6 +116,8 @@ struct TraceParams {
   const TileDev* tiles;     // otherwise
   float* out;               // final buffer (slices == 1) or partial-sum buffer
   int resolve;              // apply x*(1/spp), sqrt, clamp on the way out (slices == 1 only)
+  uint32_t bvh_stack;       // RT_FLAG_ACCEL: rows of the traversal stack (levels of the tree)
+  int bvh_in_lds;           // RT_FLAG_ACCEL: the workgroup keeps a copy of the hierarchy in LDS
   int accumulate;           // slices == 1 only: an item's running sum starts from what `out`
                             // already holds instead of zero (progressive rendering)
   float inv_spp;
@@ -153,7 +156,8 @@ struct HookParams {
 };
 
 // Launchers implemented in rt_kernels.hip.  `strict` selects the non-contracted discriminant.
-size_t trace_lds_bytes(uint32_t n_spheres, bool accel);
+size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint32_t bvh_depth,
+                       bool* bvh_in_lds);
 uint32_t bvh_stack_depth();
 hipError_t trace_max_blocks_per_cu(bool strict, bool multi, bool accel, size_t lds_bytes, int* out);
 hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, int blocks,

@@ -599,8 +599,33 @@ __device__ __forceinline__ bool bvh_box(const BvhRay& r, const float4 lo, const 
   return !(tf < tn) && !(tf < kTMin * 0.999f) && !(tn > closest);
 }
 
+// Where the traversal reads nodes and leaf records: global memory, or copies in LDS when the
+// whole hierarchy fits beside the stacks (IN_LDS; explicit LDS loads, because a load through
+// the generic pointer would take the slow path).
+struct BvhSource {
+  const float4* nodes;        // two float4 per node
+  const float4* leaf_geom;
+  const uint32_t* leaf_index;
+};
+template <bool IN_LDS>
+__device__ __forceinline__ float4 bvh_load4(const float4* p) {
+  if (IN_LDS) {
+    typedef float lds_f4 __attribute__((ext_vector_type(4)));
+    const lds_f4 v = *(const __attribute__((address_space(3))) lds_f4*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *p;
+}
+template <bool IN_LDS>
+__device__ __forceinline__ uint32_t bvh_load1(const uint32_t* p) {
+  if (IN_LDS) return *(const __attribute__((address_space(3))) uint32_t*)p;
+  return *p;
+}
+
 // `stack` is this thread's column of a [kBvhStack][kThreads] LDS array.
-__device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, uint32_t* stack) {
+template <bool IN_LDS>
+__device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, const BvhSource& src,
+                                        uint32_t* stack) {
   if (!P.alive) return;
   const V3 o = mk(P.ox, P.oy, P.oz), d = mk(P.dx, P.dy, P.dz);
   float closest = kTMax;
@@ -616,7 +641,8 @@ __device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, uint32_t* s
   ReplayBounds rb = replay_bounds(closest, P.a);
   const BvhInfo& bi = sc.bvh_info;
   for (uint32_t k = 0; k < bi.n_big; ++k)
-    candidate_hit(sc.leaf_geom[k], sc.leaf_index[k], o, d, P.a, rb, closest, best);
+    candidate_hit(bvh_load4<IN_LDS>(src.leaf_geom + k), bvh_load1<IN_LDS>(src.leaf_index + k), o, d,
+                  P.a, rb, closest, best);
   if (bi.n_nodes != 0) {
     BvhRay r;
     r.o = o;
@@ -624,38 +650,42 @@ __device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, uint32_t* s
     r.a = P.a;
     r.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     r.margin = bvh_margin(bi, o);
-    const float4* nodes = reinterpret_cast<const float4*>(sc.bvh);
+    const float4* nodes = src.nodes;
     int sp = 0;
-    uint32_t node = 0;
+    // (a, b) of the node in hand; its box was tested when it was chosen (the root's is not
+    // tested at all: its children's are)
+    uint32_t a = __float_as_uint(bvh_load4<IN_LDS>(nodes).w);
+    uint32_t b = __float_as_uint(bvh_load4<IN_LDS>(nodes + 1).w);
     for (;;) {
-      const float4 n0 = nodes[2 * node], n1 = nodes[2 * node + 1];
-      const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
       bool pop = true;
       if (b & kBvhLeaf) {
         const uint32_t count = b & ~kBvhLeaf;
         for (uint32_t k = 0; k < count; ++k)
-          candidate_hit(sc.leaf_geom[a + k], sc.leaf_index[a + k], o, d, P.a, rb, closest, best);
+          candidate_hit(bvh_load4<IN_LDS>(src.leaf_geom + a + k),
+                        bvh_load1<IN_LDS>(src.leaf_index + a + k), o, d, P.a, rb, closest, best);
       } else {
-        const float4 l0 = nodes[2 * a], l1 = nodes[2 * a + 1];
-        const float4 r0 = nodes[2 * b], r1 = nodes[2 * b + 1];
+        const float4 l0 = bvh_load4<IN_LDS>(nodes + 2 * a), l1 = bvh_load4<IN_LDS>(nodes + 2 * a + 1);
+        const float4 r0 = bvh_load4<IN_LDS>(nodes + 2 * b), r1 = bvh_load4<IN_LDS>(nodes + 2 * b + 1);
         float tl, tr;
         const bool hl = bvh_box(r, l0, l1, closest, &tl);
         const bool hr = bvh_box(r, r0, r1, closest, &tr);
-        if (hl && hr) {
-          const bool left_first = !(tr < tl);
-          stack[sp * kThreads] = left_first ? b : a;
-          sp++;
-          node = left_first ? a : b;
-          pop = false;
-        } else if (hl || hr) {
-          node = hl ? a : b;
+        if (hl || hr) {
+          const bool left = hl && (!hr || !(tr < tl));
+          if (hl && hr) {
+            stack[sp * kThreads] = left ? b : a;   // the farther child waits
+            sp++;
+          }
+          a = __float_as_uint(left ? l0.w : r0.w);
+          b = __float_as_uint(left ? l1.w : r1.w);
           pop = false;
         }
       }
       if (pop) {
         if (sp == 0) break;
         sp--;
-        node = stack[sp * kThreads];
+        const uint32_t node = stack[sp * kThreads];
+        a = __float_as_uint(bvh_load4<IN_LDS>(nodes + 2 * node).w);
+        b = __float_as_uint(bvh_load4<IN_LDS>(nodes + 2 * node + 1).w);
       }
     }
   }
@@ -793,8 +823,16 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
   return s;
 }
 
+// ACCEL (the hierarchy instead of the scan) runs ONE path per lane: two paths per lane exist to
+// share the scan's sphere reads, and a traversal shares nothing, so the registers are better
+// spent on twice the waves per SIMD to hide its dependent loads.
+#ifndef RT_ACCEL_MIN_WAVES
+#define RT_ACCEL_MIN_WAVES 8
+#endif
 template <bool STRICT, bool MULTI, bool ACCEL = false>
-__global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(kThreads, ACCEL ? RT_ACCEL_MIN_WAVES : RT_MIN_WAVES)
+void trace_kernel(const TraceParams p) {
+  constexpr int RP = ACCEL ? 1 : R;   // paths per lane
   extern __shared__ float4 lds[];
   const uint32_t n = p.scene.n_spheres;
   const uint32_t cap = lds_capacity(n);
@@ -809,12 +847,32 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
     stage_chunk(p.scene, 0, n, sph, sr2);
     __syncthreads();
   }
-  // ACCEL: the LDS holds the traversal stacks instead, one column per thread
-  uint32_t* bvh_stack = reinterpret_cast<uint32_t*>(lds) + threadIdx.x;
+  // ACCEL: the LDS holds the traversal stacks instead, one column per thread, and behind them
+  // a copy of the hierarchy when the host found room for it
+  uint32_t* bvh_stack = reinterpret_cast<uint32_t*>(lds) + threadIdx.x;   // p.bvh_stack rows
+  BvhSource bvh_src;
+  bvh_src.nodes = reinterpret_cast<const float4*>(p.scene.bvh);
+  bvh_src.leaf_geom = p.scene.leaf_geom;
+  bvh_src.leaf_index = p.scene.leaf_index;
+  if (ACCEL && p.bvh_in_lds) {
+    float4* nodes_lds = lds + p.bvh_stack * kThreads / 4;
+    float4* geom_lds = nodes_lds + 2 * p.scene.bvh_info.n_nodes;
+    uint32_t* index_lds = reinterpret_cast<uint32_t*>(geom_lds + n);
+    for (uint32_t i = threadIdx.x; i < 2 * p.scene.bvh_info.n_nodes; i += kThreads)
+      nodes_lds[i] = bvh_src.nodes[i];
+    for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
+      geom_lds[i] = p.scene.leaf_geom[i];
+      index_lds[i] = p.scene.leaf_index[i];
+    }
+    bvh_src.nodes = nodes_lds;
+    bvh_src.leaf_geom = geom_lds;
+    bvh_src.leaf_index = index_lds;
+    __syncthreads();
+  }
 
-  Path P[R];
+  Path P[RP];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
+  for (int r = 0; r < RP; ++r) {
     P[r].alive = false;
     P[r].has_item = false;
     P[r].sample = P[r].sample_end = 0;
@@ -838,7 +896,7 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
   for (;;) {
     // ---- refill: next sample of the item, or the next item ------------------------------
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RP; ++r) {
       const bool need = !P[r].alive && P[r].sample >= P[r].sample_end;
       if (need && P[r].has_item) {
         write_item(P[r], p);
@@ -853,7 +911,7 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
     }
     bool any_alive = false;
 #pragma unroll
-    for (int r = 0; r < R; ++r) any_alive = any_alive || P[r].alive;
+    for (int r = 0; r < RP; ++r) any_alive = any_alive || P[r].alive;
     const bool wave_alive = __builtin_amdgcn_ballot_w64(any_alive) != 0;
     if (MULTI) {
       if (!__syncthreads_or(wave_alive ? 1 : 0)) break;   // workgroup-uniform
@@ -866,7 +924,7 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
 
     // ---- World::hit --------------------------------------------------------------------
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RP; ++r) {
       P[r].closest = kTMax;
       P[r].best = kNone;
       P[r].cnt = 0;
@@ -881,16 +939,16 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
       uint32_t live = 0;
       bool odd = false;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
+      for (int r = 0; r < RP; ++r) {
         live += __builtin_popcountll(__builtin_amdgcn_ballot_w64(P[r].alive));
         odd = odd || (P[r].alive && P[r].degenerate);
       }
       tail = live <= kTailPaths && __builtin_amdgcn_ballot_w64(odd) == 0;
     }
-    if (ACCEL) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) bvh_hit(P[r], p.scene, bvh_stack);
-    } else if (MULTI) {
+    if constexpr (ACCEL) {
+      if (p.bvh_in_lds) bvh_hit<true>(P[0], p.scene, bvh_src, bvh_stack);
+      else bvh_hit<false>(P[0], p.scene, bvh_src, bvh_stack);
+    } else if constexpr (MULTI) {
       for (uint32_t base = 0; base < n; base += kChunkSpheres) {
         const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
         __syncthreads();   // every wave is done with the previous chunk
@@ -911,7 +969,7 @@ __global__ __launch_bounds__(kThreads, RT_MIN_WAVES) void trace_kernel(const Tra
 
     // ---- the rest of shoot_ray's body ----------------------------------------------------
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
+    for (int r = 0; r < RP; ++r) {
       if (P[r].alive) {
         n_rays++;
         const V3 o = mk(P[r].ox, P[r].oy, P[r].oz), d = mk(P[r].dx, P[r].dy, P[r].dz);
@@ -1049,7 +1107,11 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   }
   const uint32_t n = p.scene.n_spheres;
   if (p.accel) {
-    bvh_hit(P[0], p.scene, reinterpret_cast<uint32_t*>(lds) + threadIdx.x);
+    BvhSource bvh_src;
+    bvh_src.nodes = reinterpret_cast<const float4*>(p.scene.bvh);
+    bvh_src.leaf_geom = p.scene.leaf_geom;
+    bvh_src.leaf_index = p.scene.leaf_index;
+    bvh_hit<false>(P[0], p.scene, bvh_src, reinterpret_cast<uint32_t*>(lds) + threadIdx.x);
   } else {
     for (uint32_t base = 0; base < n; base += kChunkSpheres) {
       const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
@@ -1099,8 +1161,17 @@ constexpr size_t kQueueBytes = (size_t)kWavesPerWg * R * Q * kWave * sizeof(uint
 
 }  // namespace
 
-size_t trace_lds_bytes(uint32_t n_spheres, bool accel) {
-  if (accel) return (size_t)kBvhStack * kThreads * sizeof(uint32_t);
+size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint32_t bvh_depth,
+                       bool* bvh_in_lds) {
+  if (accel) {
+    // one stack row per level of the tree (at least one), four workgroups per CU
+    const size_t stacks = (size_t)(bvh_depth ? bvh_depth : 1) * kThreads * sizeof(uint32_t);
+    const size_t copy = (size_t)bvh_nodes * sizeof(BvhNode) +
+                        (size_t)n_spheres * (sizeof(float4) + sizeof(uint32_t));
+    const bool fits = stacks + copy <= kLdsPerWorkgroup / 2;
+    if (bvh_in_lds) *bvh_in_lds = fits;
+    return fits ? stacks + copy : stacks;
+  }
   return (size_t)lds_capacity(n_spheres) * (sizeof(float4) + sizeof(float)) + kQueueBytes;
 }
 
@@ -1122,7 +1193,8 @@ hipError_t trace_max_blocks_per_cu(bool strict, bool multi, bool accel, size_t l
 hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, int blocks,
                         hipStream_t stream) {
   const bool multi = p.scene.n_spheres > kChunkSpheres;
-  const size_t lds = trace_lds_bytes(p.scene.n_spheres, accel);
+  const size_t lds = trace_lds_bytes(p.scene.n_spheres, accel, p.scene.bvh_info.n_nodes,
+                                     p.bvh_stack, nullptr);
   const dim3 grid(blocks), block(kThreads);
   if (accel) {
     hipLaunchKernelGGL((trace_kernel<false, false, true>), grid, block, lds, stream, p);
