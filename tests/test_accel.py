@@ -123,3 +123,36 @@ def test_images_equal_the_scan(glass):
     both = ~(np.isnan(a) | np.isnan(b))
     assert np.array_equal(np.isnan(a), np.isnan(b))
     assert np.array_equal(a[both].view(np.uint32), b[both].view(np.uint32))
+
+
+def test_grazing_rays_are_not_pruned():
+    """Rays aimed at the silhouettes of spheres, a hair inside and a hair outside, from near and
+    far: where the reference's computed discriminant is noise, the traversal must still reach
+    every sphere the scan's exact arithmetic accepts."""
+    s, m = O.random_world(1, -11, 11)
+    scene = hip.Scene(s, m)
+    rs = np.random.default_rng(11)
+    n = 6000
+    pick = rs.integers(0, len(s), size=n)
+    c = np.stack([s["x"][pick], s["y"][pick], s["z"][pick]], axis=1).astype(np.float64)
+    r = s["radius"][pick].astype(np.float64)
+    dist = np.where(rs.random(n) < 0.5, rs.uniform(0.5, 30, n), rs.uniform(100, 3000, n))
+    dirs = rs.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    org = c + dirs * (r + dist)[:, None]
+    # a point on the silhouette circle as seen from org, nudged by a relative 1e-7 .. 1e-3
+    t = rs.normal(size=(n, 3))
+    t -= (t * dirs).sum(axis=1, keepdims=True) * dirs
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    nudge = 1.0 + rs.choice([-1, 1], size=n) * 10.0 ** rs.uniform(-7, -3, n)
+    target = c + t * (r * nudge)[:, None]
+    d = (target - org) * rs.uniform(0.2, 2.0, size=(n, 1))
+    rays = np.zeros(n, dtype=abi.RAY_IN_DTYPE)
+    rays["ox"], rays["oy"], rays["oz"] = org.astype(np.float32).T
+    rays["dx"], rays["dy"], rays["dz"] = d.astype(np.float32).T
+    brute = hip.trace_rays(scene, rays, seed=3, flags=0)
+    accel = hip.trace_rays(scene, rays, seed=3, flags=ACCEL)
+    same_records(brute, accel)
+    grazed = (brute["hit"] == 1) & (brute["sphere"] == pick)   # the aimed-at sphere is the hit
+    assert 0.1 * n < grazed.sum() < 0.9 * n
+    scene.close()
