@@ -202,7 +202,7 @@ def main():
     flop = FLOP_PER_TEST * n_spheres * st.rays
     achieved = flop / (kernel_ms * 1e-3) * 1e-12 if kernel_ms > 0 else 0.0
 
-    kernel_name = "rt::trace_kernel<false,%s>" % ("true" if n_spheres > 2016 else "false")
+    kernel_name = "rt::trace_kernel<false,%s,false>" % ("true" if n_spheres > 2016 else "false")
     if rank == 0:
         samples_per_step = W * H * spp
         value = samples_per_step * args.steps / elapsed * 1e-6
@@ -238,7 +238,8 @@ def main():
                 "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
                 "traffic": profiled_traffic(args.config, kernel_name) if world == 1 else None,
                 "traffic_source": "profiles/round1/%s_pmc_per_launch.csv (rocprofv3 --pmc, bytes "
-                                  "per launch of an earlier run of this command)" % args.config,
+                                  "per launch of an earlier run of this command; null when that "
+                                  "file is absent or N > 1)" % args.config,
                 "kernel": kernel_name,
                 "kernel_ms": round(kernel_ms, 3),
                 "kernel_ms_source": kernel_ms_source,

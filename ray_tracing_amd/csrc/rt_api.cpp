@@ -133,6 +133,9 @@ float trigger_constant(const rt_sphere& s) {
 
 int check_ready() {
   if (!g.ready) return fail(RT_ERR_NOT_INITIALIZED, "rt_init() has not been called");
+  // every call below allocates, copies or launches on the library's device, whatever device
+  // the caller made current in between
+  RT_HIP(hipSetDevice(g.device));
   return RT_OK;
 }
 
@@ -244,6 +247,9 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   p.total_items = (uint32_t)(total_pixels * p.slices);
   p.out_pixels = out_pixels;
   p.inv_spp = 1.0f / (float)frame->samples_per_pixel;   // `1.0 / spp as f32`, src/cpu/mod.rs:67
+  if (scene->device != g.device)
+    return fail(RT_ERR_INVALID_ARGUMENT, "scene lives on device %d, the library on device %d",
+                scene->device, g.device);
   LaunchSlot* slot = nullptr;
   if (int rc = acquire_slot(stream, &slot)) return rc;
   p.counters = slot->counters;
