@@ -36,6 +36,9 @@
 //  * STRICT = true makes the scan evaluate the discriminant literally, in the reference's
 //    operation order without fused multiply-adds (17 instructions).  Both modes give the same
 //    bits; STRICT exists to check the conservative scan against the literal one.
+//  * ACCEL = true (opt-in, RT_FLAG_ACCEL) replaces scan and replay by a per-lane traversal of a
+//    bounding-volume hierarchy built on the host (rt_bvh.cpp), one path per lane; everything
+//    around World::hit is the same code.  Same bits again: see bvh_hit.
 //
 // Build flags that matter: -ffp-contract=off (every fma below is written out by hand),
 // -fno-slp-vectorize (auto-packing into v_pk_*_f32 costs more shuffles than it saves here).
