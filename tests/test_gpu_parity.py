@@ -375,3 +375,15 @@ def test_dielectric_heavy_1024spp_image_accuracy():
     assert psnr2 >= 32.0
     for a, b in means2:
         assert abs(a - b) <= 0.005 * abs(b)
+
+
+def test_white_furnace_conserves_energy_on_the_gpu():
+    from test_oracle_known_answers import check_white_furnace, white_furnace_world
+    s, m = white_furnace_world()
+    w, h, spp = 160, 90, 64
+    cam = default_camera(w / h)
+    tiles = O.job_queue(w, h, 64, 64)
+    for flags in (0, abi.RT_FLAG_ACCEL):
+        sums = hip.render_tiles(s, m, cam, w, h, spp, 50, 4, tiles, flags=flags)
+        st = hip.get_stats()
+        check_white_furnace(sums, spp, st.rays, st.samples)

@@ -530,6 +530,44 @@ def test_empty_world_image_is_the_sky_gradient():
     assert np.all(np.diff(red) < 0)
 
 
+def white_furnace_world():
+    """Ground plus three spheres, every one diffuse with albedo exactly 1: a path's throughput
+    stays 1, so whatever it returns is a sky colour - blue exactly 1, red and green in [0.5, 1]
+    - or black if it runs out of depth.  Energy is neither lost nor gained in the diffuse branch."""
+    s = np.zeros(4, dtype=abi.SPHERE_DTYPE)
+    m = np.zeros(1, dtype=abi.MATERIAL_DTYPE)
+    m[0] = (1.0, 1.0, 1.0, 0, 0.0, 0.0)
+    s[0] = (0.0, -1000.0, 0.0, 1000.0, 0)
+    s[1] = (0.0, 1.0, 0.0, 1.0, 0)
+    s[2] = (-4.0, 1.0, 0.0, 1.0, 0)
+    s[3] = (4.0, 1.0, 0.0, 1.0, 0)
+    return s, m
+
+
+def check_white_furnace(sums, spp, rays, samples):
+    per_sample = sums / F32(spp)
+    assert not np.isnan(sums).any()
+    # blue: every finished path adds s*1 + t*1 with s = 1 - t, i.e. 1 to within an ulp
+    assert np.all(per_sample[..., 2] <= 1.0 + 1e-6)
+    assert np.all(per_sample[..., 0] <= 1.0 + 1e-6) and np.all(per_sample[..., 1] <= 1.0 + 1e-6)
+    # at most a few paths in a thousand die at max_depth 50 between the spheres and the ground
+    assert per_sample[..., 2].mean() > 0.995
+    # red and green between the horizon's white and the zenith's (0.5, 0.7)
+    assert np.all(per_sample[..., 0] >= 0.5 * per_sample[..., 2] - 1e-6)
+    assert np.all(per_sample[..., 1] >= 0.7 * per_sample[..., 2] - 1e-6)
+    assert rays > 2 * samples        # the furnace does bounce
+
+
+def test_white_furnace_conserves_energy():
+    s, m = white_furnace_world()
+    cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, 16 / 9)
+    w, h, spp = 64, 36, 32
+    tiles = O.job_queue(w, h, 64, 64)
+    _, _, ctr, sums = O.render(s, m, cam, w, h, spp, 50, 4, mode=O.RO_MODE_RECURSIVE, threads=8,
+                               tiles=tiles, want_sums=True)
+    check_white_furnace(sums, spp, ctr.rays, ctr.samples)
+
+
 def test_bmp_writer(tmp_path):
     fb = np.zeros((2, 3, 3), dtype=F32)
     fb[0, 0] = (1.0, 0.5, 0.0)       # bottom-left pixel of the picture
