@@ -32,13 +32,13 @@ PEAK_FP32_VALU_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz 
 FLOP_PER_TEST = 17              # one ray/sphere discriminant, src/main.rs:131-135 with a hoisted
 
 CONFIGS = {
-    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    # the configuration the headline metric is quoted on
     "rtiow488_1080p_100spp_d50": dict(grid=(-11, 11), width=1920, height=1080, spp=100, depth=50),
-    # configs[2]: same scene at 4K, 500 spp
+    # same scene at 4K, 500 spp
     "rtiow488_2160p_500spp_d50": dict(grid=(-11, 11), width=3840, height=2160, spp=500, depth=50),
-    # configs[3]: 10 004 spheres, LDS-chunked scan
+    # 10 004 spheres, LDS-chunked scan
     "rtiow10k_1080p_64spp_d50": dict(grid=(-50, 50), width=1920, height=1080, spp=64, depth=50),
-    # configs[4]: dielectric-heavy
+    # dielectric-heavy
     "glass488_1080p_1024spp_d50": dict(grid=(-11, 11), width=1920, height=1080, spp=1024, depth=50,
                                        diffuse_below=0.1, metal_below=0.2, glass=True),
 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Kernel time and roofline fraction of every BASELINE configuration (and the reference's own
+# Kernel time and roofline fraction of every benchmark configuration (and the reference's own
 # 68-sphere scene and one rank's share of the 1080p frame at 8 GPUs), one line per launch.
 set -e -o pipefail
 out=gpurun_out/$1
