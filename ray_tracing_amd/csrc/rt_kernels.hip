@@ -560,14 +560,18 @@ __device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, uint3
 // Sphere::hit arithmetic and World::hit's minimum-t / later-sphere-wins rule, which does not
 // depend on the visiting order.  So the result is the linear scan's, bit for bit, as long as no
 // sphere is pruned that the reference's arithmetic would accept.  A sphere (c, r) is accepted
-// only if its COMPUTED discriminant is >= 0 and its computed root lies in [t_min, closest].
-// With u = 2^-24 and S = |o-c|^2 + r^2 the computed discriminant is within 22u |d|^2 S of the
-// exact one, so the ray's line passes within r + 11u S / r of c; and the computed root is within
-// sqrt(22u S) + 8u |o-c| (as a distance) of a point of that widened sphere.  A box that holds
-// the sphere, widened by the sum of the two, therefore holds the computed hit point, and a slab
-// test against it (with a relative 1e-5 on its own rounding) brackets the computed root.  The
-// margin below is twice that sum, with |o-c| bounded by the distance to the ball that holds all
-// centres and r by the tree's smallest and largest radius.
+// only if its COMPUTED discriminant is >= 0 and its computed root t lies in [t_min, closest].
+// With u = 2^-24, S = |o-c|^2 + r^2, a = |d|^2, hb = (o-c).d, hb' its computed value and s the
+// computed square root, the point at t = (-hb' +- s) / a satisfies, identically,
+//   |o + t d - c|^2 = r^2 + (s^2 - disc_exact) / a + ((hb - hb')^2 +- 2 s (hb - hb')) / a.
+// s^2 is the computed discriminant to within 2u of itself, which is within 22u a S of the exact
+// one, and |hb - hb'| <= 4u |o-c| |d| with s <= |o-c| |d|: the right-hand side is at most
+// r^2 + 32u S, so that point lies within r + 16u S / r of c (plus the rounding of t itself,
+// below 8u (|o-c| + r)).  A box that holds the sphere, widened by that
+// much, therefore holds the point at the computed root, and a slab test against it (with a
+// relative 1e-5 on its own rounding) brackets that root.  The margin below is twice the bound,
+// with |o-c| taken up to the distance to the ball that holds all centres and r between the
+// tree's smallest and largest radius.
 constexpr int kBvhStack = 24;   // balanced median splits: depth <= log2(n) <= 24
 
 struct BvhRay {
@@ -580,7 +584,7 @@ __device__ __forceinline__ float bvh_margin(const BvhInfo& bi, V3 o) {
   const V3 oc = sub(o, mk(bi.centre[0], bi.centre[1], bi.centre[2]));
   const float dist = __builtin_sqrtf(dot(oc, oc)) * 1.000001f + bi.extent;
   const float S = dist * dist + bi.r_max * bi.r_max;
-  return 2.0f * (11.0f * u * S / bi.r_min + __builtin_sqrtf(22.0f * u * S) + 8.0f * u * dist);
+  return 2.0f * (16.0f * u * S / bi.r_min + 8.0f * u * (dist + bi.r_max));
 }
 
 // Does the ray reach the widened box within [t_min, closest]?  *t_near is its entry parameter.
@@ -951,6 +955,7 @@ void trace_kernel(const TraceParams p) {
     if constexpr (ACCEL) {
       if (p.bvh_in_lds) bvh_hit<true>(P[0], p.scene, bvh_src, bvh_stack);
       else bvh_hit<false>(P[0], p.scene, bvh_src, bvh_stack);
+      RT_STAMP(clk.scan, clk.t0);   // the traversal is this mode's "scan"
     } else if constexpr (MULTI) {
       for (uint32_t base = 0; base < n; base += kChunkSpheres) {
         const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
