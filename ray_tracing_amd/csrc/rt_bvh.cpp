@@ -12,7 +12,7 @@
 // Layout: spheres much larger than the typical one (the ground, the three big spheres) would
 // bloat every box above them, so they are kept out of the tree and tested for every ray
 // (leaf slots [0, n_big)).  The rest is split top-down at the median centre along the longest
-// axis of the centres' bounds until a node holds at most kLeafSpheres; leaves index a
+// axis of the centres' bounds until a node holds at most kLeafSpheres (8: measured against 1, 2 and 4); leaves index a
 // permuted copy of (cx, cy, cz, r*r) with the original sphere numbers beside it.
 #include <algorithm>
 #include <cmath>
@@ -25,7 +25,10 @@ namespace rt {
 
 namespace {
 
-constexpr uint32_t kLeafSpheres = 4;
+#ifndef RT_BVH_LEAF
+#define RT_BVH_LEAF 8
+#endif
+constexpr uint32_t kLeafSpheres = RT_BVH_LEAF;
 
 struct Builder {
   const rt_sphere* s;
