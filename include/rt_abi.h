@@ -180,6 +180,14 @@ int rt_render(const rt_request* req, float* out_rgb);
  * tile, row-major inside the tile: the UN-NORMALISED sums of JobResult.pixel_colors. */
 int rt_render_tiles(const rt_request* req, float* out_sums);
 
+/* The same loop cut into passes: adds samples [sample_begin, sample_begin +
+ * req->samples_per_pixel) of every pixel to the sums inout_sums already holds (layout of
+ * rt_render_tiles).  `pixel_color += color` (src/cpu/job.rs:58) is additive and the division by
+ * the sample count happens later (src/cpu/mod.rs:67), so a host can render progressively, stop
+ * on a time budget, or checkpoint the sums; the reference itself renders in one pass.  See
+ * rt_accumulate_device_async for what the passes add up to. */
+int rt_accumulate_tiles(const rt_request* req, uint32_t sample_begin, float* inout_sums);
+
 /* Replaces compose_final_framebuffer (reference src/cpu/mod.rs:51-83) for callers that kept the
  * per-tile sums: scatters the tiles into out_rgb (W*H*3) applying x*(1/spp), sqrt, clamp. */
 int rt_compose(const rt_tile* tiles, uint32_t n_tiles, const float* tile_sums,

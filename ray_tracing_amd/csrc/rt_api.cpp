@@ -737,7 +737,22 @@ int rt_render(const rt_request* req, float* out_rgb) {
   return RT_OK;
 }
 
+namespace {
+// rt_render_tiles, and rt_accumulate_tiles when `inout` (the sums are uploaded first and the
+// call adds samples [sample_begin, sample_begin + spp) to them).
+int render_tiles_host(const rt_request* req, float* out_sums, bool inout, uint32_t sample_begin);
+}  // namespace
+
 int rt_render_tiles(const rt_request* req, float* out_sums) {
+  return render_tiles_host(req, out_sums, false, 0);
+}
+
+int rt_accumulate_tiles(const rt_request* req, uint32_t sample_begin, float* inout_sums) {
+  return render_tiles_host(req, inout_sums, true, sample_begin);
+}
+
+namespace {
+int render_tiles_host(const rt_request* req, float* out_sums, bool inout, uint32_t sample_begin) {
   if (int rc = check_ready()) return rc;
   if (int rc = check_request(req, true)) return rc;
   rt_frame f = frame_of(req);
@@ -759,13 +774,20 @@ int rt_render_tiles(const rt_request* req, float* out_sums) {
   const size_t bytes = (size_t)total * 3 * sizeof(float);
   ScopedDev d;
   RT_HIP(hipMalloc(&d.p, bytes));
-  if (int rc = rt_render_device_async(sc.s, &f, req->tiles, off.data(), stride.data(), req->n_tiles,
-                                      0, (float*)d.p, g.stream))
+  if (inout) {
+    RT_HIP(hipMemcpy(d.p, out_sums, bytes, hipMemcpyHostToDevice));
+    if (int rc = rt_accumulate_device_async(sc.s, &f, sample_begin, req->tiles, off.data(),
+                                            stride.data(), req->n_tiles, (float*)d.p, g.stream))
+      return rc;
+  } else if (int rc = rt_render_device_async(sc.s, &f, req->tiles, off.data(), stride.data(),
+                                             req->n_tiles, 0, (float*)d.p, g.stream)) {
     return rc;
+  }
   RT_HIP(hipStreamSynchronize(g.stream));
   RT_HIP(hipMemcpy(out_sums, d.p, bytes, hipMemcpyDeviceToHost));
   return RT_OK;
 }
+}  // namespace
 
 int rt_compose(const rt_tile* tiles, uint32_t n_tiles, const float* tile_sums, uint32_t image_width,
                uint32_t image_height, uint32_t samples_per_pixel, float* out_rgb) {

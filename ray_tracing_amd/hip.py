@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 # every symbol include/rt_abi.h declares
 EXPORTS = (
     "rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version",
-    "rt_render", "rt_render_tiles", "rt_compose",
+    "rt_render", "rt_render_tiles", "rt_accumulate_tiles", "rt_compose",
     "rt_scene_create", "rt_scene_destroy",
     "rt_render_device_async", "rt_render_rows_device_async",
     "rt_accumulate_device_async", "rt_resolve_device_async",
@@ -76,6 +76,7 @@ def lib():
     L.rt_abi_version.argtypes = []
     L.rt_render.argtypes = [C.POINTER(abi.RtRequest), vp]
     L.rt_render_tiles.argtypes = [C.POINTER(abi.RtRequest), vp]
+    L.rt_accumulate_tiles.argtypes = [C.POINTER(abi.RtRequest), u32, vp]
     L.rt_compose.argtypes = [vp, u32, vp, u32, u32, u32, vp]
     L.rt_scene_create.argtypes = [vp, u32, vp, u32, C.POINTER(vp)]
     L.rt_scene_destroy.argtypes = [vp]
@@ -175,6 +176,16 @@ def render_tiles(spheres, materials, camera, width, height, spp, max_depth, seed
     out = np.empty((n, 3), dtype=np.float32)
     check(lib().rt_render_tiles(C.byref(req), abi.ptr(out)))
     return out
+
+
+def accumulate_tiles(spheres, materials, camera, width, height, spp, max_depth, seed, tiles,
+                     sample_begin, sums, flags=0):
+    """rt_accumulate_tiles: adds samples [sample_begin, sample_begin + spp) to `sums` in place."""
+    req, keep = make_request(spheres, materials, camera, width, height, spp, max_depth, seed, flags,
+                             tiles)
+    assert sums.dtype == np.float32 and sums.flags["C_CONTIGUOUS"]
+    check(lib().rt_accumulate_tiles(C.byref(req), int(sample_begin), abi.ptr(sums)))
+    return sums
 
 
 def compose(tiles, tile_sums, width, height, spp):

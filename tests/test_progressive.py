@@ -91,6 +91,22 @@ def test_sequential_passes_are_bit_identical_to_one_render(flags):
 
 
 @pytest.mark.gpu
+def test_host_pointer_passes_are_bit_identical_to_one_render():
+    hip.init(0)
+    w, h, depth, seed = 48, 27, 50, 6
+    s, m, cam = scene_and_camera(w, h)
+    tiles = O.job_queue(w, h, 32, 32)
+    _, _, _, ref = O.render(s, m, cam, w, h, 7, depth, seed, mode=O.RO_MODE_ITER_MUL, threads=8,
+                            tiles=tiles, want_sums=True)
+    sums = np.zeros_like(ref)
+    begin = 0
+    for n in (3, 4):
+        hip.accumulate_tiles(s, m, cam, w, h, n, depth, seed, tiles, begin, sums, flags=SEQ)
+        begin += n
+    assert np.array_equal(sums.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
 def test_sliced_passes_add_exactly_and_agree_with_one_render():
     import torch
     hip.init(0)
