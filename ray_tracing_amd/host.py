@@ -29,6 +29,7 @@ HOST_EXPORTS = (
     "rth_last_error", "rth_camera_new", "rth_create_random_world", "rth_create_simple_world",
     "rth_create_job_queue", "rth_debug_write_job_queue_to_framebuffer",
     "rth_compose_final_framebuffer", "rth_write_framebuffer_to_image", "rth_dispatch_work_gpu",
+    "rth_dispatch_work_gpu_progressive",
 )
 
 _lib = None
@@ -57,6 +58,9 @@ def lib():
     L.rth_write_framebuffer_to_image.argtypes = [C.c_char_p, u32, u32, vp]
     L.rth_dispatch_work_gpu.argtypes = [vp, u32, u32, u32, u32, u32, C.POINTER(abi.RtCamera),
                                         vp, u32, vp, u32, u32, u32, vp]
+    L.rth_dispatch_work_gpu_progressive.argtypes = [vp, u32, u32, u32, u32, vp, u32,
+                                                    C.POINTER(abi.RtCamera), vp, u32, vp, u32,
+                                                    u32, u32, vp]
     _lib = L
     return L
 
@@ -188,6 +192,20 @@ def dispatch_work_gpu(dispatch, num_gpus=1, seed=1, flags=0):
                                        len(d.world.spheres), abi.ptr(d.world.materials),
                                        len(d.world.materials), int(seed) & 0xFFFFFFFF, int(flags),
                                        abi.ptr(out)))
+    return out
+
+
+def dispatch_work_gpu_progressive_host(dispatch, passes, seed=1, flags=0):
+    """cpu::dispatch_work_gpu_progressive of the C++ mirror: the passes go through the
+    host-pointer entry point rt_accumulate_tiles and the frame is composed at the end."""
+    d = dispatch
+    p = np.ascontiguousarray(passes, dtype=np.uint32)
+    out = np.zeros((d.image_height, d.image_width, 3), dtype=np.float32)
+    _check(lib().rth_dispatch_work_gpu_progressive(
+        abi.ptr(d.job_queue), len(d.job_queue), d.image_width, d.image_height, d.max_depth,
+        abi.ptr(p), len(p), C.byref(d.camera.m), abi.ptr(d.world.spheres), len(d.world.spheres),
+        abi.ptr(d.world.materials), len(d.world.materials), int(seed) & 0xFFFFFFFF, int(flags),
+        abi.ptr(out)))
     return out
 
 

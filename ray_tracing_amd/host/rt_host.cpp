@@ -343,6 +343,34 @@ std::vector<Vec3> dispatch_work_gpu(const Dispatch& dispatch, uint32_t seed, uin
   return framebuffer;
 }
 
+std::vector<Vec3> dispatch_work_gpu_progressive(const Dispatch& dispatch,
+                                                const std::vector<std::size_t>& passes,
+                                                uint32_t seed, uint32_t flags,
+                                                bool (*on_pass)(std::size_t)) {
+  std::vector<rt_sphere> s;
+  std::vector<rt_material> m;
+  std::vector<rt_tile> tiles;
+  rt_request req = make_request(dispatch, seed, flags, s, m, tiles);
+  std::size_t total = 0;
+  for (const rt_tile& t : tiles) total += (std::size_t)t.width * t.height;
+  std::vector<float> sums(total * 3, 0.0f);
+  std::size_t done = 0;
+  for (std::size_t n : passes) {
+    if (n == 0) continue;
+    req.samples_per_pixel = (uint32_t)n;
+    require(rt_accumulate_tiles(&req, (uint32_t)done, sums.data()), "rt_accumulate_tiles");
+    done += n;
+    if (on_pass && !on_pass(done)) break;
+  }
+  if (done == 0) throw std::runtime_error("dispatch_work_gpu_progressive: no samples rendered");
+  std::vector<Vec3> framebuffer(dispatch.image_width * dispatch.image_height);
+  require(rt_compose(tiles.data(), (uint32_t)tiles.size(), sums.data(), (uint32_t)dispatch.image_width,
+                     (uint32_t)dispatch.image_height, (uint32_t)done,
+                     reinterpret_cast<float*>(framebuffer.data())),
+          "rt_compose");
+  return framebuffer;
+}
+
 std::vector<JobResult> execute_jobs_gpu(const Dispatch& dispatch, uint32_t seed, uint32_t flags) {
   std::vector<rt_sphere> s;
   std::vector<rt_material> m;
@@ -573,6 +601,26 @@ int rth_dispatch_work_gpu(const rt_tile* jobs, uint32_t n_jobs, uint32_t image_w
         queue_from_abi(jobs, n_jobs), image_width, image_height, max_depth, samples_per_pixel, cam,
         world_from_abi(spheres, n_spheres, materials, n_materials));
     const auto fb = rt_host::cpu::dispatch_work_gpu(d, seed, flags);
+    std::memcpy(out_rgb, fb.data(), fb.size() * sizeof(rt_host::Vec3));
+  });
+}
+
+// cpu::dispatch_work_gpu_progressive over POD inputs; passes[k] samples per pixel in pass k.
+int rth_dispatch_work_gpu_progressive(const rt_tile* jobs, uint32_t n_jobs, uint32_t image_width,
+                                      uint32_t image_height, uint32_t max_depth,
+                                      const uint32_t* passes, uint32_t n_passes,
+                                      const rt_camera* camera, const rt_sphere* spheres,
+                                      uint32_t n_spheres, const rt_material* materials,
+                                      uint32_t n_materials, uint32_t seed, uint32_t flags,
+                                      float* out_rgb) {
+  return guarded([&] {
+    rt_host::Camera cam;
+    cam.m = *camera;
+    const auto d = rt_host::cpu::Dispatch::create(
+        queue_from_abi(jobs, n_jobs), image_width, image_height, max_depth, 1, cam,
+        world_from_abi(spheres, n_spheres, materials, n_materials));
+    std::vector<std::size_t> p(passes, passes + n_passes);
+    const auto fb = rt_host::cpu::dispatch_work_gpu_progressive(d, p, seed, flags);
     std::memcpy(out_rgb, fb.data(), fb.size() * sizeof(rt_host::Vec3));
   });
 }

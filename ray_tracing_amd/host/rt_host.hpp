@@ -118,6 +118,14 @@ std::vector<Vec3> compose_final_framebuffer(std::size_t image_width, std::size_t
 std::vector<Vec3> dispatch_work_gpu(const Dispatch& dispatch, uint32_t seed, uint32_t flags = 0);
 // The tile loop on the GPU: one JobResult (un-normalised sums) per job of the queue.
 std::vector<JobResult> execute_jobs_gpu(const Dispatch& dispatch, uint32_t seed, uint32_t flags = 0);
+// The same contract rendered in passes of `passes[k]` samples per pixel that add into the
+// per-tile sums (`pixel_color += color`, src/cpu/job.rs:58), composed once at the end with the
+// number of samples actually rendered (src/cpu/mod.rs:67); dispatch.samples_per_pixel is not
+// used.  `on_pass(samples_done)` may return false to stop early.
+std::vector<Vec3> dispatch_work_gpu_progressive(const Dispatch& dispatch,
+                                                const std::vector<std::size_t>& passes,
+                                                uint32_t seed, uint32_t flags = 0,
+                                                bool (*on_pass)(std::size_t) = nullptr);
 
 }  // namespace cpu
 

@@ -177,6 +177,10 @@ def test_host_progressive_dispatch_matches_one_pass_and_honours_a_time_budget():
     fb, done = host.dispatch_work_gpu_progressive(d, [4, 4, 4], seed=seed, flags=SEQ,
                                                   on_pass=lambda n, sums: seen.append(n))
     assert done == 12 and seen == [4, 8, 12]
+    via_host = host.dispatch_work_gpu_progressive_host(d, [5, 7], seed=seed, flags=SEQ)
+    ok_h = ~(np.isnan(one) | np.isnan(via_host))
+    assert np.array_equal(np.isnan(one), np.isnan(via_host))
+    assert np.array_equal(via_host[ok_h].view(np.uint32), one[ok_h].view(np.uint32))
     both = ~(np.isnan(one) | np.isnan(fb))
     assert np.array_equal(np.isnan(one), np.isnan(fb))
     assert np.array_equal(fb[both].view(np.uint32), one[both].view(np.uint32))
