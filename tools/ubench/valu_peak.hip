@@ -354,6 +354,80 @@ __global__ void k_mix(const float4* __restrict__ spheres, int n, int reps, float
   out[tid] = (float)cnt;
 }
 
+
+// ---- 6. the same two forms with the production loop's read-ahead: the next block's records are
+// read from LDS (into a second register set) while the current block is evaluated.
+template <int R, bool PK>
+__global__ void k_cons_ahead(const float4* __restrict__ spheres, int n, int reps, float* out) {
+  extern __shared__ float4 lds[];
+  for (int i = threadIdx.x; i < n + 8; i += blockDim.x) lds[i] = spheres[i < n ? i : 0];
+  __syncthreads();
+  constexpr int RP = R / 2;
+  float ox[R], oy[R], oz[R], nx[R], ny[R], nz[R], od[R], noo[R];
+  f2 pox[RP], poy[RP], poz[RP], pnx[RP], pny[RP], pnz[RP], pod[RP], pnoo[RP];
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned h = (tid * R + r) * 2654435761u;
+    ox[r] = 13.f + (h & 255) * 1e-3f; oy[r] = 2.f + ((h >> 8) & 255) * 1e-3f; oz[r] = 3.f + (h & 7) * 1e-3f;
+    nx[r] = 0.96f - ((h >> 16) & 255) * 1e-3f; ny[r] = 0.15f + (h & 3) * 1e-3f; nz[r] = 0.22f - (h >> 24) * 1e-3f;
+    od[r] = -(ox[r] * nx[r] + oy[r] * ny[r] + oz[r] * nz[r]);
+    noo[r] = -(ox[r] * ox[r] + oy[r] * oy[r] + oz[r] * oz[r]);
+  }
+#pragma unroll
+  for (int p = 0; p < RP; ++p) {
+    pox[p] = f2{ox[2 * p], ox[2 * p + 1]}; poy[p] = f2{oy[2 * p], oy[2 * p + 1]}; poz[p] = f2{oz[2 * p], oz[2 * p + 1]};
+    pnx[p] = f2{nx[2 * p], nx[2 * p + 1]}; pny[p] = f2{ny[2 * p], ny[2 * p + 1]}; pnz[p] = f2{nz[2 * p], nz[2 * p + 1]};
+    pod[p] = f2{od[2 * p], od[2 * p + 1]}; pnoo[p] = f2{noo[2 * p], noo[2 * p + 1]};
+  }
+  int cnt = 0;
+  const f2 two = {2.0f, 2.0f};
+  auto block = [&](const float4 (&s)[4]) {
+    int m = (int)0x80000000;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (PK) {
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+          f2 hb = __builtin_elementwise_fma(f2(s[u].z), pnz[p], __builtin_elementwise_fma(f2(s[u].y), pny[p],
+                  __builtin_elementwise_fma(f2(s[u].x), pnx[p], pod[p])));
+          f2 qh = __builtin_elementwise_fma(f2(s[u].z), poz[p], __builtin_elementwise_fma(f2(s[u].y), poy[p],
+                  __builtin_elementwise_fma(f2(s[u].x), pox[p], f2(s[u].w))));
+          f2 disc = __builtin_elementwise_fma(hb, hb, __builtin_elementwise_fma(qh, two, pnoo[p]));
+          m = max(m, max(__float_as_int(disc.x), __float_as_int(disc.y)));
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float hb = __builtin_fmaf(s[u].z, nz[r], __builtin_fmaf(s[u].y, ny[r], __builtin_fmaf(s[u].x, nx[r], od[r])));
+          float qh = __builtin_fmaf(s[u].z, oz[r], __builtin_fmaf(s[u].y, oy[r], __builtin_fmaf(s[u].x, ox[r], s[u].w)));
+          float disc = __builtin_fmaf(hb, hb, __builtin_fmaf(qh, 2.0f, noo[r]));
+          m = max(m, __float_as_int(disc));
+        }
+      }
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= 0) != 0, 0)) cnt += (m >= 0);
+  };
+  for (int rep = 0; rep < reps; ++rep) {
+    float4 A[4], B[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) A[u] = lds[u];
+    for (int i = 0; i + 8 <= n; i += 8) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) B[u] = lds[i + 4 + u];
+      __builtin_amdgcn_sched_barrier(0);
+      block(A);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) A[u] = lds[i + 8 + u];
+      __builtin_amdgcn_sched_barrier(0);
+      block(B);
+    }
+    ox[0] += 1e-6f;
+    if (PK) pox[0] += 1e-6f;
+  }
+  out[tid] = (float)cnt;
+}
+
 static float time_ms(hipEvent_t e0, hipEvent_t e1) { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
 
 int main(int argc, char** argv) {
@@ -428,6 +502,37 @@ int main(int argc, char** argv) {
       run("mix1+4", (k_mix<4, 1>), 128, wps, 256);
       run("mix1+8", (k_mix<8, 1>), 192, wps, 256);
       run("mix1+6", (k_mix<6, 1>), 160, wps, 256);
+    }
+    return 0;
+  }
+
+
+  if (argc > 2 && !strcmp(argv[2], "ahead")) {
+    const int n = 488, reps = 400;
+    std::vector<float4> hs(n);
+    for (int i = 0; i < n; ++i) hs[i] = make_float4((i % 22) - 11 + 0.3f, 0.2f, (i / 22) - 11 + 0.4f, -1e6f);
+    float4* ds; CK(hipMalloc(&ds, sizeof(float4) * n));
+    CK(hipMemcpy(ds, hs.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    auto run = [&](const char* name, auto kern, int R, int wps, int threads) {
+      int blocks = cus * wps * 256 / threads;
+      float best = 1e30f;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), (n + 8) * sizeof(float4), 0, ds, n, reps, out);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms = time_ms(e0, e1);
+        if (ms < best) best = ms;
+      }
+      CK(hipGetLastError());
+      double tests = (double)blocks * threads * R * n * reps;
+      printf("%-14s paths/lane %d waves/SIMD %d : %8.3f ms  %7.2f Gtests/s  = %5.1f%% of 157.3 TF at 17 flop/test\n",
+             name, R, wps, best, tests / best * 1e-6, tests * 17 / best * 1e-9 / 157.3 * 100);
+    };
+    for (int wps : {2, 4, 8}) {
+      run("ahead", (k_cons_ahead<2, false>), 2, wps, 256);
+      run("ahead_pk", (k_cons_ahead<2, true>), 2, wps, 256);
+      run("ahead", (k_cons_ahead<4, false>), 4, wps, 256);
+      run("ahead_pk", (k_cons_ahead<4, true>), 4, wps, 256);
     }
     return 0;
   }
