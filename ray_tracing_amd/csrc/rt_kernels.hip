@@ -632,7 +632,7 @@ __device__ __forceinline__ uint32_t bvh_load1(const uint32_t* p) {
 // `stack` is this thread's column of a [kBvhStack][kThreads] LDS array.
 template <bool IN_LDS>
 __device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, const BvhSource& src,
-                                        uint32_t* stack) {
+                                        uint32_t* stack, uint32_t& n_interior, uint32_t& n_tests) {
   if (!P.alive) return;
   const V3 o = mk(P.ox, P.oy, P.oz), d = mk(P.dx, P.dy, P.dz);
   float closest = kTMax;
@@ -667,10 +667,16 @@ __device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, const BvhSo
       bool pop = true;
       if (b & kBvhLeaf) {
         const uint32_t count = b & ~kBvhLeaf;
+#ifdef RT_DIAG_PHASES
+        n_tests += count;
+#endif
         for (uint32_t k = 0; k < count; ++k)
           candidate_hit(bvh_load4<IN_LDS>(src.leaf_geom + a + k),
                         bvh_load1<IN_LDS>(src.leaf_index + a + k), o, d, P.a, rb, closest, best);
       } else {
+#ifdef RT_DIAG_PHASES
+        n_interior++;
+#endif
         const float4 l0 = bvh_load4<IN_LDS>(nodes + 2 * a), l1 = bvh_load4<IN_LDS>(nodes + 2 * a + 1);
         const float4 r0 = bvh_load4<IN_LDS>(nodes + 2 * b), r1 = bvh_load4<IN_LDS>(nodes + 2 * b + 1);
         float tl, tr;
@@ -894,6 +900,7 @@ void trace_kernel(const TraceParams p) {
   uint32_t grab_next = 0, grab_end = 0;
   bool exhausted = false;
   uint32_t n_rays = 0, n_samples = 0;
+  uint32_t bvh_interior = 0, bvh_tests = 0;   // diagnostic build: nodes opened, spheres tested
   PhaseClock clk = {};
 #ifdef RT_DIAG_PHASES
   clk.t0 = __builtin_amdgcn_s_memtime();
@@ -953,8 +960,8 @@ void trace_kernel(const TraceParams p) {
       tail = live <= kTailPaths && __builtin_amdgcn_ballot_w64(odd) == 0;
     }
     if constexpr (ACCEL) {
-      if (p.bvh_in_lds) bvh_hit<true>(P[0], p.scene, bvh_src, bvh_stack);
-      else bvh_hit<false>(P[0], p.scene, bvh_src, bvh_stack);
+      if (p.bvh_in_lds) bvh_hit<true>(P[0], p.scene, bvh_src, bvh_stack, bvh_interior, bvh_tests);
+      else bvh_hit<false>(P[0], p.scene, bvh_src, bvh_stack, bvh_interior, bvh_tests);
       RT_STAMP(clk.scan, clk.t0);   // the traversal is this mode's "scan"
     } else if constexpr (MULTI) {
       for (uint32_t base = 0; base < n; base += kChunkSpheres) {
@@ -1030,6 +1037,13 @@ void trace_kernel(const TraceParams p) {
     atomicMax(&p.counters->phase[11], clk.tail_steps);
     atomicAdd(&p.counters->phase[12], clk.tail_cycles);          // cycles inside tail_hit
     atomicAdd(&p.counters->phase[13], 1ull);                     // waves
+  }
+  {
+    const unsigned long long bi = wave_sum(bvh_interior), bt = wave_sum(bvh_tests);
+    if (lane == 0) {
+      atomicAdd(&p.counters->phase[14], bi);                     // hierarchy: interior nodes opened
+      atomicAdd(&p.counters->phase[15], bt);                     // hierarchy: leaf spheres tested
+    }
   }
 #endif
   const unsigned long long rays = wave_sum(n_rays);
@@ -1119,7 +1133,9 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     bvh_src.nodes = reinterpret_cast<const float4*>(p.scene.bvh);
     bvh_src.leaf_geom = p.scene.leaf_geom;
     bvh_src.leaf_index = p.scene.leaf_index;
-    bvh_hit<false>(P[0], p.scene, bvh_src, reinterpret_cast<uint32_t*>(lds) + threadIdx.x);
+    uint32_t unused_a = 0, unused_b = 0;
+    bvh_hit<false>(P[0], p.scene, bvh_src, reinterpret_cast<uint32_t*>(lds) + threadIdx.x, unused_a,
+                   unused_b);
   } else {
     for (uint32_t base = 0; base < n; base += kChunkSpheres) {
       const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
