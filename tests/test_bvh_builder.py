@@ -1,0 +1,65 @@
+"""The host-side hierarchy builder (ray_tracing_amd/csrc/rt_bvh.cpp) checked on the CPU: a small
+native program links the builder, builds a tree for spheres given on stdin and verifies the
+invariants the GPU traversal relies on (every sphere in exactly one leaf or in the always-tested
+list, boxes nested and holding their spheres, reported depth, the ball and radius range behind
+the per-ray margin)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path_factory.mktemp("bvh") / "bvh_check")
+    cmd = [HIPCC, "-O1", "-std=c++17", "-x", "hip", "--offload-arch=gfx950",
+           os.path.join(ROOT, "tests", "native", "bvh_check.cpp"),
+           os.path.join(ROOT, "ray_tracing_amd", "csrc", "rt_bvh.cpp"), "-o", out]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    return out
+
+
+def run(checker, spheres):
+    text = "".join("%r %r %r %r\n" % (float(s[0]), float(s[1]), float(s[2]), float(s[3]))
+                   for s in spheres)
+    p = subprocess.run([checker], input=text, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    tag, nodes, depth, n_big = p.stdout.split()
+    assert tag == "ok"
+    return int(nodes), int(depth), int(n_big)
+
+
+def rows(s):
+    return np.stack([s["x"], s["y"], s["z"], s["radius"]], axis=1)
+
+
+@pytest.mark.parametrize("grid,expect_big", [((-4, 4), 4), ((-11, 11), 4), ((-50, 50), 4)])
+def test_reference_scenes(checker, grid, expect_big):
+    s, _ = O.random_world(1, *grid)
+    nodes, depth, n_big = run(checker, rows(s))
+    assert n_big == expect_big                  # the ground and the three unit spheres
+    n_small = len(s) - n_big
+    assert depth <= int(np.ceil(np.log2(max(n_small, 2)))) + 1 <= 24
+    assert nodes <= 2 * n_small
+
+
+def test_degenerate_inputs(checker):
+    assert run(checker, np.zeros((0, 4))) == (0, 0, 0)
+    assert run(checker, [[1, 2, 3, 0.5]]) == (1, 1, 0)
+    # forty coincident spheres still split into leaves of at most eight
+    nodes, depth, n_big = run(checker, [[0, 0.2, 0, 0.2]] * 40)
+    assert n_big == 0 and depth <= 6
+    # zero and negative radii, huge coordinates
+    rs = np.random.default_rng(3)
+    pts = rs.uniform(-1e6, 1e6, size=(200, 3))
+    rad = rs.choice([0.0, -0.3, 0.2, 5.0], size=(200, 1))
+    run(checker, np.hstack([pts, rad]))
