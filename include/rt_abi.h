@@ -174,6 +174,16 @@ int rt_abi_version(void);
  * fb[x + y*W], y = 0 at the bottom, each channel clamp(sqrt(sum/spp), 0, 0.999). */
 int rt_render(const rt_request* req, float* out_rgb);
 
+/* rt_render over several GPUs driven by ONE process, which is what the reference's host is.
+ * Rows are dealt to devices[0..n_devices) in blocks of 8, round-robin (the reference deals
+ * tiles to `num_threads` workers, src/cpu/multi.rs:30-62, 140-141); every device renders its
+ * blocks at the same time and the blocks are copied straight into out_rgb, so there is no
+ * device-to-device exchange.  Pixels are keyed by their position in the whole frame: the result
+ * is bit-identical to rt_render's for any device list (a device may be listed more than once).
+ * rt_init() must have been called; the listed devices get contexts of their own, kept until
+ * rt_shutdown(). */
+int rt_render_multi(const rt_request* req, const int* devices, int n_devices, float* out_rgb);
+
 /* Replaces the loop `for job in queue { execute_job(&job, &data) }` (reference
  * src/cpu/job.rs:36-74 as driven by src/cpu/single.rs:17-39 / src/cpu/multi.rs:30-62).
  * out_sums receives, tile after tile in the order of req->tiles, width*height RGB triples per

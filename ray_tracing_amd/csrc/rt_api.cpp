@@ -79,31 +79,37 @@ struct State {
   int last_slot = -1;
   rt::TileDev* tiles = nullptr;           // device, grow-only
   size_t tiles_cap = 0;
-  std::vector<rt::TileDev> tiles_host;    // what g.tiles currently holds
+  std::vector<rt::TileDev> tiles_host;    // what ctx().tiles currently holds
   hipEvent_t ev_begin[kEventRing], ev_end[kEventRing];
   uint64_t launches = 0;
 };
-State g;
+// One State per GPU the process drives.  Context 0 is the one rt_init() makes; rt_render_multi
+// adds one per listed device and puts it in charge (ctx()) around the calls it makes for that
+// device.  Everything else in this file just says ctx().
+State g_primary;
+std::vector<State*> g_extra;     // contexts of rt_render_multi, by position in its device list
+State* g_cur = &g_primary;
+inline State& ctx() { return *g_cur; }
 
 int acquire_slot(hipStream_t stream, LaunchSlot** out) {
   int pick = -1;
   for (int i = 0; i < kLaunchSlots; ++i)
-    if (g.slots[i].bound && g.slots[i].stream == stream) pick = i;
+    if (ctx().slots[i].bound && ctx().slots[i].stream == stream) pick = i;
   if (pick < 0) {
     for (int i = 0; i < kLaunchSlots && pick < 0; ++i)
-      if (!g.slots[i].bound) pick = i;
+      if (!ctx().slots[i].bound) pick = i;
     if (pick < 0) {
       pick = 0;
       for (int i = 1; i < kLaunchSlots; ++i)
-        if (g.slots[i].last_use < g.slots[pick].last_use) pick = i;
-      RT_HIP(hipStreamSynchronize(g.slots[pick].stream));   // its buffers may still be in use
+        if (ctx().slots[i].last_use < ctx().slots[pick].last_use) pick = i;
+      RT_HIP(hipStreamSynchronize(ctx().slots[pick].stream));   // its buffers may still be in use
     }
-    g.slots[pick].stream = stream;
-    g.slots[pick].bound = true;
+    ctx().slots[pick].stream = stream;
+    ctx().slots[pick].bound = true;
   }
-  g.slots[pick].last_use = g.launches + 1;
-  g.last_slot = pick;
-  *out = &g.slots[pick];
+  ctx().slots[pick].last_use = ctx().launches + 1;
+  ctx().last_slot = pick;
+  *out = &ctx().slots[pick];
   return RT_OK;
 }
 
@@ -132,10 +138,10 @@ float trigger_constant(const rt_sphere& s) {
 }
 
 int check_ready() {
-  if (!g.ready) return fail(RT_ERR_NOT_INITIALIZED, "rt_init() has not been called");
+  if (!ctx().ready) return fail(RT_ERR_NOT_INITIALIZED, "rt_init() has not been called");
   // every call below allocates, copies or launches on the library's device, whatever device
   // the caller made current in between
-  RT_HIP(hipSetDevice(g.device));
+  RT_HIP(hipSetDevice(ctx().device));
   return RT_OK;
 }
 
@@ -247,9 +253,9 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   p.total_items = (uint32_t)(total_pixels * p.slices);
   p.out_pixels = out_pixels;
   p.inv_spp = 1.0f / (float)frame->samples_per_pixel;   // `1.0 / spp as f32`, src/cpu/mod.rs:67
-  if (scene->device != g.device)
+  if (scene->device != ctx().device)
     return fail(RT_ERR_INVALID_ARGUMENT, "scene lives on device %d, the library on device %d",
-                scene->device, g.device);
+                scene->device, ctx().device);
   LaunchSlot* slot = nullptr;
   if (int rc = acquire_slot(stream, &slot)) return rc;
   p.counters = slot->counters;
@@ -275,23 +281,23 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   } else {
     // The table lives in one grow-only device buffer.  A caller that renders the same tile
     // list frame after frame (a rank's row blocks) pays for the upload once.
-    const bool same = g.tiles_host.size() == tiles.size() &&
-                      memcmp(g.tiles_host.data(), tiles.data(), tiles.size() * sizeof(rt::TileDev)) == 0;
+    const bool same = ctx().tiles_host.size() == tiles.size() &&
+                      memcmp(ctx().tiles_host.data(), tiles.data(), tiles.size() * sizeof(rt::TileDev)) == 0;
     if (!same) {
       RT_HIP(hipDeviceSynchronize());   // an earlier launch, on any stream, may still read it
-      if (tiles.size() > g.tiles_cap) {
-        if (g.tiles) RT_HIP(hipFree(g.tiles));
-        g.tiles = nullptr;
-        g.tiles_cap = 0;
-        g.tiles_host.clear();
-        RT_HIP(hipMalloc((void**)&g.tiles, tiles.size() * sizeof(rt::TileDev)));
-        g.tiles_cap = tiles.size();
+      if (tiles.size() > ctx().tiles_cap) {
+        if (ctx().tiles) RT_HIP(hipFree(ctx().tiles));
+        ctx().tiles = nullptr;
+        ctx().tiles_cap = 0;
+        ctx().tiles_host.clear();
+        RT_HIP(hipMalloc((void**)&ctx().tiles, tiles.size() * sizeof(rt::TileDev)));
+        ctx().tiles_cap = tiles.size();
       }
-      RT_HIP(hipMemcpy(g.tiles, tiles.data(), tiles.size() * sizeof(rt::TileDev),
+      RT_HIP(hipMemcpy(ctx().tiles, tiles.data(), tiles.size() * sizeof(rt::TileDev),
                        hipMemcpyHostToDevice));
-      g.tiles_host = tiles;
+      ctx().tiles_host = tiles;
     }
-    p.tiles = g.tiles;
+    p.tiles = ctx().tiles;
   }
 
   float* trace_out = d_out;
@@ -322,7 +328,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   int per_cu = 0;
   RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, accel, lds, &per_cu));
   if (per_cu < 1) return fail(RT_ERR_DEVICE, "trace kernel does not fit on a CU (LDS %zu B)", lds);
-  int blocks = per_cu * g.cus;
+  int blocks = per_cu * ctx().cus;
   const uint32_t paths_per_lane = accel ? 1 : rt::kRaysPerLane;
   const uint64_t lanes_needed = ((uint64_t)p.total_items + paths_per_lane - 1) / paths_per_lane;
   const uint64_t blocks_needed = (lanes_needed + rt::kThreads - 1) / rt::kThreads;
@@ -330,11 +336,11 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   if (blocks < 1) blocks = 1;
 
   RT_HIP(hipMemsetAsync(slot->counters, 0, sizeof(rt::Counters), stream));
-  const int ev = (int)(g.launches % kEventRing);
-  RT_HIP(hipEventRecord(g.ev_begin[ev], stream));
+  const int ev = (int)(ctx().launches % kEventRing);
+  RT_HIP(hipEventRecord(ctx().ev_begin[ev], stream));
   RT_HIP(rt::launch_trace(p, strict, accel, blocks, stream));
-  RT_HIP(hipEventRecord(g.ev_end[ev], stream));
-  g.launches++;
+  RT_HIP(hipEventRecord(ctx().ev_end[ev], stream));
+  ctx().launches++;
   slot->event = ev;
 
   if (p.slices > 1) {
@@ -410,11 +416,9 @@ int rt_abi_version(void) { return RT_ABI_VERSION; }
 
 const char* rt_last_error(void) { return g_error.c_str(); }
 
-int rt_init(int device) {
-  if (g.ready) {
-    if (g.device == device) return RT_OK;
-    return fail(RT_ERR_INVALID_ARGUMENT, "already initialised on device %d", g.device);
-  }
+namespace {
+// Brings the context in charge up on `device`.
+int init_context(int device) {
   int count = 0;
   RT_HIP(hipGetDeviceCount(&count));
   if (device < 0 || device >= count)
@@ -425,37 +429,58 @@ int rt_init(int device) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(RT_ERR_DEVICE, "device %d is %s; this library holds gfx950 code only", device,
                 prop.gcnArchName);
-  g.cus = prop.multiProcessorCount;
-  RT_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-  for (LaunchSlot& sl : g.slots) {
+  ctx().cus = prop.multiProcessorCount;
+  RT_HIP(hipStreamCreateWithFlags(&ctx().stream, hipStreamNonBlocking));
+  for (LaunchSlot& sl : ctx().slots) {
     RT_HIP(hipMalloc((void**)&sl.counters, sizeof(rt::Counters)));
     RT_HIP(hipMemset(sl.counters, 0, sizeof(rt::Counters)));
   }
   for (int i = 0; i < kEventRing; ++i) {
-    RT_HIP(hipEventCreate(&g.ev_begin[i]));
-    RT_HIP(hipEventCreate(&g.ev_end[i]));
+    RT_HIP(hipEventCreate(&ctx().ev_begin[i]));
+    RT_HIP(hipEventCreate(&ctx().ev_end[i]));
   }
-  g.device = device;
-  g.launches = 0;
-  g.ready = true;
+  ctx().device = device;
+  ctx().launches = 0;
+  ctx().ready = true;
   return RT_OK;
 }
 
-int rt_shutdown(void) {
-  if (!g.ready) return RT_OK;
-  (void)hipSetDevice(g.device);
+void destroy_context() {
+  if (!ctx().ready) return;
+  (void)hipSetDevice(ctx().device);
   (void)hipDeviceSynchronize();
   for (int i = 0; i < kEventRing; ++i) {
-    (void)hipEventDestroy(g.ev_begin[i]);
-    (void)hipEventDestroy(g.ev_end[i]);
+    (void)hipEventDestroy(ctx().ev_begin[i]);
+    (void)hipEventDestroy(ctx().ev_end[i]);
   }
-  for (LaunchSlot& sl : g.slots) {
+  for (LaunchSlot& sl : ctx().slots) {
     if (sl.counters) (void)hipFree(sl.counters);
     if (sl.partial) (void)hipFree(sl.partial);
   }
-  if (g.tiles) (void)hipFree(g.tiles);
-  if (g.stream) (void)hipStreamDestroy(g.stream);
-  g = State();
+  if (ctx().tiles) (void)hipFree(ctx().tiles);
+  if (ctx().stream) (void)hipStreamDestroy(ctx().stream);
+  ctx() = State();
+}
+}  // namespace
+
+int rt_init(int device) {
+  g_cur = &g_primary;
+  if (ctx().ready) {
+    if (ctx().device == device) return RT_OK;
+    return fail(RT_ERR_INVALID_ARGUMENT, "already initialised on device %d", ctx().device);
+  }
+  return init_context(device);
+}
+
+int rt_shutdown(void) {
+  for (State* ctx : g_extra) {
+    g_cur = ctx;
+    destroy_context();
+    delete ctx;
+  }
+  g_extra.clear();
+  g_cur = &g_primary;
+  destroy_context();
   return RT_OK;
 }
 
@@ -478,7 +503,7 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
     if (!(mag < 1e37))
       return fail(RT_ERR_LIMIT, "sphere %u: centre or radius not finite or beyond 1e18", i);
   }
-  RT_HIP(hipSetDevice(g.device));
+  RT_HIP(hipSetDevice(ctx().device));
 
   std::vector<float4> trig(n_spheres ? n_spheres : 1);
   std::vector<float4> geom(n_spheres ? n_spheres : 1);
@@ -500,7 +525,7 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
     mat[2 * m + 1] = make_float4(materials[m].metallic_strength, materials[m].ir, 0.0f, 0.0f);
   }
   rt_scene* s = new rt_scene();
-  s->device = g.device;
+  s->device = ctx().device;
   ScopedScene guard;
   guard.s = s;
   RT_HIP(hipMalloc(&s->trig, trig.size() * sizeof(float4)));
@@ -599,7 +624,7 @@ int rt_render_device_async(const rt_scene* scene, const rt_frame* frame, const r
   std::vector<rt::TileDev> td;
   uint64_t out_pixels = 0;
   if (int rc = tile_table(frame, tiles, out_offset, out_stride, n_tiles, &td, &out_pixels)) return rc;
-  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
   return render_tiles_device(scene, frame, td, out_pixels, resolve, d_out, s);
 }
 
@@ -618,7 +643,7 @@ int rt_accumulate_device_async(const rt_scene* scene, const rt_frame* frame, uin
   std::vector<rt::TileDev> td;
   uint64_t out_pixels = 0;
   if (int rc = tile_table(frame, tiles, out_offset, out_stride, n_tiles, &td, &out_pixels)) return rc;
-  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
   return render_tiles_device(scene, frame, td, out_pixels, 0, d_sums, s, sample_begin, true);
 }
 
@@ -633,7 +658,7 @@ int rt_resolve_device_async(const float* d_sums, uint64_t n_pixels, uint32_t sam
   rp.out = d_rgb;
   rp.n_pixels = n_pixels;
   rp.inv_spp = 1.0f / (float)samples_per_pixel;   // `1.0 / spp as f32`, src/cpu/mod.rs:67
-  RT_HIP(rt::launch_resolve(rp, stream ? (hipStream_t)stream : g.stream));
+  RT_HIP(rt::launch_resolve(rp, stream ? (hipStream_t)stream : ctx().stream));
   return RT_OK;
 }
 
@@ -654,24 +679,24 @@ int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame, ui
   t.out_stride = frame->image_width;
   t.out_offset = 0;
   std::vector<rt::TileDev> td(1, t);
-  hipStream_t s = stream ? (hipStream_t)stream : g.stream;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
   return render_tiles_device(scene, frame, td, (uint64_t)t.w * t.h, resolve, d_out, s);
 }
 
 int rt_synchronize(void* stream) {
   if (int rc = check_ready()) return rc;
-  RT_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : g.stream));
+  RT_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx().stream));
   return RT_OK;
 }
 
 int rt_get_stats(rt_stats* out) {
   if (int rc = check_ready()) return rc;
   if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
-  if (g.last_slot < 0) {
+  if (ctx().last_slot < 0) {
     *out = rt_stats{};
     return RT_OK;
   }
-  const LaunchSlot& sl = g.slots[g.last_slot];
+  const LaunchSlot& sl = ctx().slots[ctx().last_slot];
   RT_HIP(hipStreamSynchronize(sl.stream));
   rt_stats s = sl.last;
   if (s.workgroups != 0) {
@@ -681,7 +706,7 @@ int rt_get_stats(rt_stats* out) {
     s.samples = c.samples;
     s.sphere_tests = c.rays * sl.last.sphere_tests;
     float ms = 0.0f;
-    RT_HIP(hipEventElapsedTime(&ms, g.ev_begin[sl.event], g.ev_end[sl.event]));
+    RT_HIP(hipEventElapsedTime(&ms, ctx().ev_begin[sl.event], ctx().ev_end[sl.event]));
     s.kernel_ms = ms;
   }
   *out = s;
@@ -693,8 +718,8 @@ int rt_get_phase_cycles(uint64_t* out16) {
   if (!out16) return fail(RT_ERR_INVALID_ARGUMENT, "out16 is NULL");
   rt::Counters c;
   memset(&c, 0, sizeof c);
-  if (g.last_slot >= 0) {
-    const LaunchSlot& sl = g.slots[g.last_slot];
+  if (ctx().last_slot >= 0) {
+    const LaunchSlot& sl = ctx().slots[ctx().last_slot];
     RT_HIP(hipStreamSynchronize(sl.stream));
     RT_HIP(hipMemcpy(&c, sl.counters, sizeof c, hipMemcpyDeviceToHost));
   }
@@ -706,13 +731,13 @@ int rt_get_launch_ms(uint32_t n_last, float* out_ms) {
   if (int rc = check_ready()) return rc;
   if (n_last && !out_ms) return fail(RT_ERR_INVALID_ARGUMENT, "out_ms is NULL");
   uint64_t n = n_last;
-  if (n > g.launches) n = g.launches;
+  if (n > ctx().launches) n = ctx().launches;
   if (n > (uint64_t)kEventRing) n = kEventRing;
   for (uint64_t k = 0; k < n; ++k) {
-    const int slot = (int)((g.launches - n + k) % kEventRing);
-    RT_HIP(hipEventSynchronize(g.ev_end[slot]));
+    const int slot = (int)((ctx().launches - n + k) % kEventRing);
+    RT_HIP(hipEventSynchronize(ctx().ev_end[slot]));
     float ms = 0.0f;
-    RT_HIP(hipEventElapsedTime(&ms, g.ev_begin[slot], g.ev_end[slot]));
+    RT_HIP(hipEventElapsedTime(&ms, ctx().ev_begin[slot], ctx().ev_end[slot]));
     out_ms[k] = ms;
   }
   return (int)n;
@@ -730,10 +755,95 @@ int rt_render(const rt_request* req, float* out_rgb) {
   const size_t bytes = (size_t)f.image_width * f.image_height * 3 * sizeof(float);
   ScopedDev d;
   RT_HIP(hipMalloc(&d.p, bytes));
-  if (int rc = rt_render_rows_device_async(sc.s, &f, 0, f.image_height, 1, (float*)d.p, g.stream))
+  if (int rc = rt_render_rows_device_async(sc.s, &f, 0, f.image_height, 1, (float*)d.p, ctx().stream))
     return rc;
-  RT_HIP(hipStreamSynchronize(g.stream));
+  RT_HIP(hipStreamSynchronize(ctx().stream));
   RT_HIP(hipMemcpy(out_rgb, d.p, bytes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+namespace {
+// Puts the primary context back in charge when a multi-device call leaves, however it leaves.
+struct ContextGuard {
+  ~ContextGuard() {
+    g_cur = &g_primary;
+    if (g_primary.ready) (void)hipSetDevice(g_primary.device);
+  }
+};
+}  // namespace
+
+int rt_render_multi(const rt_request* req, const int* devices, int n_devices, float* out_rgb) {
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_request(req, false)) return rc;
+  if (!out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
+  if (!devices || n_devices < 1 || n_devices > 64)
+    return fail(RT_ERR_INVALID_ARGUMENT, "device list of %d entries", n_devices);
+  rt_frame f = frame_of(req);
+  if (int rc = check_frame(&f)) return rc;
+  const uint32_t W = f.image_width, H = f.image_height;
+  constexpr uint32_t kBlockRows = 8;   // rows are dealt to the devices in blocks of 8, round-robin
+  const uint32_t n_blocks = (H + kBlockRows - 1) / kBlockRows;
+
+  struct Share {
+    ScopedScene scene;
+    ScopedDev buffer;
+    std::vector<rt::TileDev> tiles;
+    uint64_t pixels = 0;
+  };
+  std::vector<Share> shares(n_devices);
+  ContextGuard guard;
+
+  // enqueue every device's share; nothing below waits, so the GPUs run side by side
+  for (int k = 0; k < n_devices; ++k) {
+    while ((int)g_extra.size() <= k) g_extra.push_back(new State());
+    g_cur = g_extra[k];
+    if (ctx().ready && ctx().device != devices[k]) destroy_context();
+    if (!ctx().ready)
+      if (int rc = init_context(devices[k])) return rc;
+    RT_HIP(hipSetDevice(ctx().device));
+    Share& sh = shares[k];
+    for (uint32_t b = (uint32_t)k; b < n_blocks; b += (uint32_t)n_devices) {
+      rt::TileDev t;
+      memset(&t, 0, sizeof t);
+      t.x = 0;
+      t.y = b * kBlockRows;
+      t.w = W;
+      t.h = H - t.y < kBlockRows ? H - t.y : kBlockRows;
+      t.first_pixel = (uint32_t)sh.pixels;
+      t.out_stride = W;
+      t.out_offset = sh.pixels;
+      sh.pixels += (uint64_t)t.w * t.h;
+      sh.tiles.push_back(t);
+    }
+    if (sh.tiles.empty()) continue;
+    if (int rc = rt_scene_create(req->spheres, req->n_spheres, req->materials, req->n_materials,
+                                 &sh.scene.s))
+      return rc;
+    RT_HIP(hipMalloc(&sh.buffer.p, sh.pixels * 3 * sizeof(float)));
+    if (int rc = render_tiles_device(sh.scene.s, &f, sh.tiles, sh.pixels, 1, (float*)sh.buffer.p,
+                                     ctx().stream))
+      return rc;
+  }
+  // collect: each share's blocks go to their rows of the caller's framebuffer
+  std::vector<float> staging;
+  for (int k = 0; k < n_devices; ++k) {
+    Share& sh = shares[k];
+    if (sh.tiles.empty()) continue;
+    g_cur = g_extra[k];
+    RT_HIP(hipSetDevice(ctx().device));
+    RT_HIP(hipStreamSynchronize(ctx().stream));
+    staging.resize(sh.pixels * 3);
+    RT_HIP(hipMemcpy(staging.data(), sh.buffer.p, sh.pixels * 3 * sizeof(float),
+                     hipMemcpyDeviceToHost));
+    for (const rt::TileDev& t : sh.tiles)
+      memcpy(out_rgb + (size_t)t.y * W * 3, staging.data() + t.out_offset * 3,
+             (size_t)t.w * t.h * 3 * sizeof(float));
+    // free this device's buffers while its context is the one in charge
+    RT_HIP(hipFree(sh.buffer.p));
+    sh.buffer.p = nullptr;
+    (void)rt_scene_destroy(sh.scene.s);
+    sh.scene.s = nullptr;
+  }
   return RT_OK;
 }
 
@@ -777,13 +887,13 @@ int render_tiles_host(const rt_request* req, float* out_sums, bool inout, uint32
   if (inout) {
     RT_HIP(hipMemcpy(d.p, out_sums, bytes, hipMemcpyHostToDevice));
     if (int rc = rt_accumulate_device_async(sc.s, &f, sample_begin, req->tiles, off.data(),
-                                            stride.data(), req->n_tiles, (float*)d.p, g.stream))
+                                            stride.data(), req->n_tiles, (float*)d.p, ctx().stream))
       return rc;
   } else if (int rc = rt_render_device_async(sc.s, &f, req->tiles, off.data(), stride.data(),
-                                             req->n_tiles, 0, (float*)d.p, g.stream)) {
+                                             req->n_tiles, 0, (float*)d.p, ctx().stream)) {
     return rc;
   }
-  RT_HIP(hipStreamSynchronize(g.stream));
+  RT_HIP(hipStreamSynchronize(ctx().stream));
   RT_HIP(hipMemcpy(out_sums, d.p, bytes, hipMemcpyDeviceToHost));
   return RT_OK;
 }
@@ -838,8 +948,8 @@ int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays,
   if (hp.accel && scene->bvh_depth > rt::bvh_stack_depth())
     return fail(RT_ERR_LIMIT, "hierarchy of %u levels exceeds the traversal stack (%u)",
                 scene->bvh_depth, rt::bvh_stack_depth());
-  RT_HIP(rt::launch_hook(hp, (flags & RT_FLAG_STRICT_FP) != 0, g.stream));
-  RT_HIP(hipStreamSynchronize(g.stream));
+  RT_HIP(rt::launch_hook(hp, (flags & RT_FLAG_STRICT_FP) != 0, ctx().stream));
+  RT_HIP(hipStreamSynchronize(ctx().stream));
   RT_HIP(hipMemcpy(out, dout.p, (size_t)n_rays * sizeof(rt_ray_out), hipMemcpyDeviceToHost));
   return RT_OK;
 }

@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "librt_hip.so")
 # every symbol include/rt_abi.h declares
 EXPORTS = (
     "rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version",
-    "rt_render", "rt_render_tiles", "rt_accumulate_tiles", "rt_compose",
+    "rt_render", "rt_render_multi", "rt_render_tiles", "rt_accumulate_tiles", "rt_compose",
     "rt_scene_create", "rt_scene_destroy",
     "rt_render_device_async", "rt_render_rows_device_async",
     "rt_accumulate_device_async", "rt_resolve_device_async",
@@ -75,6 +75,7 @@ def lib():
     L.rt_last_error.restype = C.c_char_p
     L.rt_abi_version.argtypes = []
     L.rt_render.argtypes = [C.POINTER(abi.RtRequest), vp]
+    L.rt_render_multi.argtypes = [C.POINTER(abi.RtRequest), vp, i, vp]
     L.rt_render_tiles.argtypes = [C.POINTER(abi.RtRequest), vp]
     L.rt_accumulate_tiles.argtypes = [C.POINTER(abi.RtRequest), u32, vp]
     L.rt_compose.argtypes = [vp, u32, vp, u32, u32, u32, vp]
@@ -164,6 +165,15 @@ def render(spheres, materials, camera, width, height, spp, max_depth, seed, flag
     req, keep = make_request(spheres, materials, camera, width, height, spp, max_depth, seed, flags)
     out = np.empty((height, width, 3), dtype=np.float32)
     check(lib().rt_render(C.byref(req), abi.ptr(out)))
+    return out
+
+
+def render_multi(spheres, materials, camera, width, height, spp, max_depth, seed, devices, flags=0):
+    """rt_render_multi: one process, several GPUs (a device may be listed more than once)."""
+    req, keep = make_request(spheres, materials, camera, width, height, spp, max_depth, seed, flags)
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    out = np.empty((height, width, 3), dtype=np.float32)
+    check(lib().rt_render_multi(C.byref(req), abi.ptr(dev), len(dev), abi.ptr(out)))
     return out
 
 

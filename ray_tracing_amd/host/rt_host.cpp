@@ -332,14 +332,23 @@ std::vector<Vec3> compose_final_framebuffer(std::size_t image_width, std::size_t
   return framebuffer;
 }
 
-std::vector<Vec3> dispatch_work_gpu(const Dispatch& dispatch, uint32_t seed, uint32_t flags) {
+std::vector<Vec3> dispatch_work_gpu(const Dispatch& dispatch, uint32_t seed, uint32_t flags,
+                                    int num_gpus) {
   std::vector<rt_sphere> s;
   std::vector<rt_material> m;
   std::vector<rt_tile> tiles;
   const rt_request req = make_request(dispatch, seed, flags, s, m, tiles);
   static_assert(sizeof(Vec3) == 3 * sizeof(float), "Vec3 must be three packed floats");
   std::vector<Vec3> framebuffer(dispatch.image_width * dispatch.image_height);
-  require(rt_render(&req, reinterpret_cast<float*>(framebuffer.data())), "rt_render");
+  if (num_gpus > 1) {
+    std::vector<int> devices(num_gpus);
+    for (int k = 0; k < num_gpus; ++k) devices[k] = k;
+    require(rt_render_multi(&req, devices.data(), num_gpus,
+                            reinterpret_cast<float*>(framebuffer.data())),
+            "rt_render_multi");
+  } else {
+    require(rt_render(&req, reinterpret_cast<float*>(framebuffer.data())), "rt_render");
+  }
   return framebuffer;
 }
 

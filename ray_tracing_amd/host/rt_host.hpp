@@ -115,7 +115,10 @@ std::vector<Vec3> compose_final_framebuffer(std::size_t image_width, std::size_t
 
 // Whole frame on the GPU; same return contract as dispatch_work_cpu_multithreaded.  Throws
 // std::runtime_error where the reference would panic.
-std::vector<Vec3> dispatch_work_gpu(const Dispatch& dispatch, uint32_t seed, uint32_t flags = 0);
+// num_gpus plays the part of dispatch_work_cpu_multithreaded's num_threads (src/cpu/multi.rs:132):
+// with more than one, this one process drives devices 0..num_gpus-1 through rt_render_multi.
+std::vector<Vec3> dispatch_work_gpu(const Dispatch& dispatch, uint32_t seed, uint32_t flags = 0,
+                                    int num_gpus = 1);
 // The tile loop on the GPU: one JobResult (un-normalised sums) per job of the queue.
 std::vector<JobResult> execute_jobs_gpu(const Dispatch& dispatch, uint32_t seed, uint32_t flags = 0);
 // The same contract rendered in passes of `passes[k]` samples per pixel that add into the

@@ -4,7 +4,7 @@
 // multithreaded.bmp.  The wgpu experiment that precedes `return;` at src/main.rs:885 is not
 // reproduced.
 //
-// usage: rt_main [width=1920] [spp=100] [max_depth=4] [grid=4] [seed=1] [outdir=.] [flags=0]
+// usage: rt_main [width=1920] [spp=100] [max_depth=4] [grid=4] [seed=1] [outdir=.] [flags=0] [gpus=1]
 //        (flags: RT_FLAG_* of include/rt_abi.h, e.g. 4 = the opt-in hierarchy)
 #include <chrono>
 #include <cstdio>
@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
   const uint32_t seed = argc > 5 ? (uint32_t)std::strtoul(argv[5], nullptr, 10) : 1;
   const std::string outdir = argc > 6 ? argv[6] : ".";
   const uint32_t flags = argc > 7 ? (uint32_t)std::strtoul(argv[7], nullptr, 10) : 0;
+  const int num_gpus = argc > 8 ? std::atoi(argv[8]) : 1;   // num_cpus::get() in the reference
 
   const float aspect_ratio = 16.0f / 9.0f;
   const std::size_t image_height = (std::size_t)((float)image_width / aspect_ratio);
@@ -47,7 +48,7 @@ int main(int argc, char** argv) {
     const auto dispatch = cpu::Dispatch::create(job_queue, image_width, image_height, max_depth,
                                                 samples_per_pixel, camera, world);
     const auto t0 = std::chrono::steady_clock::now();
-    const auto framebuffer = cpu::dispatch_work_gpu(dispatch, seed, flags);
+    const auto framebuffer = cpu::dispatch_work_gpu(dispatch, seed, flags, num_gpus);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("Finished Jobs: 100.00\n");
     std::printf("Time: %.2f s (%lld ms)\n", secs, (long long)(secs * 1000.0));   // src/cpu/multi.rs:164-165

@@ -387,3 +387,25 @@ def test_white_furnace_conserves_energy_on_the_gpu():
         sums = hip.render_tiles(s, m, cam, w, h, spp, 50, 4, tiles, flags=flags)
         st = hip.get_stats()
         check_white_furnace(sums, spp, st.rays, st.samples)
+
+
+def test_one_process_several_devices_gives_the_same_frame():
+    """rt_render_multi deals row blocks to a list of devices driven by one process.  On a
+    one-GPU box the list names device 0 several times: each entry still gets its own context,
+    stream, scene copy and share of the rows, and the assembled frame must be rt_render's."""
+    w, h, spp = 200, 117, 8          # 15 row blocks, the last one short
+    s, m = O.random_world(1, -11, 11)
+    cam = default_camera(w / h)
+    one = hip.render(s, m, cam, w, h, spp, 50, 3)
+    for devices in ([0], [0, 0], [0, 0, 0, 0, 0], [0] * 20):
+        many = hip.render_multi(s, m, cam, w, h, spp, 50, 3, devices)
+        both = ~(np.isnan(one) | np.isnan(many))
+        assert np.array_equal(np.isnan(one), np.isnan(many))
+        assert np.array_equal(one[both].view(np.uint32), many[both].view(np.uint32))
+    with pytest.raises(hip.RtError):
+        hip.render_multi(s, m, cam, w, h, spp, 50, 3, [7])       # no such device
+    with pytest.raises(hip.RtError):
+        hip.render_multi(s, m, cam, w, h, spp, 50, 3, [])
+    # the primary context is back in charge afterwards
+    again = hip.render(s, m, cam, w, h, spp, 50, 3)
+    assert np.array_equal(np.isnan(one), np.isnan(again))
