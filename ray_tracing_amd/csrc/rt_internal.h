@@ -11,9 +11,15 @@
 namespace rt {
 
 constexpr int kWave = 64;
-constexpr int kThreads = 512;           // 8 waves per workgroup
+#ifndef RT_THREADS
+#define RT_THREADS 512
+#endif
+constexpr int kThreads = RT_THREADS;    // 8 waves per workgroup
 constexpr int kWavesPerWg = kThreads / kWave;
-constexpr int kRaysPerLane = 2;         // independent paths blocked into one lane
+#ifndef RT_RAYS_PER_LANE
+#define RT_RAYS_PER_LANE 2
+#endif
+constexpr int kRaysPerLane = RT_RAYS_PER_LANE;   // independent paths blocked into one lane
 constexpr int kQueueSlots = 20;         // deferred-candidate slots per path (u16 each)
 constexpr int kScanUnroll = 4;          // spheres per unrolled block of the scan
 constexpr uint32_t kChunkSpheres = 2016; // spheres resident in LDS at a time: with the read-ahead
