@@ -331,7 +331,8 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   int blocks = per_cu * ctx().cus;
   const uint32_t paths_per_lane = accel ? 1 : rt::kRaysPerLane;
   const uint64_t lanes_needed = ((uint64_t)p.total_items + paths_per_lane - 1) / paths_per_lane;
-  const uint64_t blocks_needed = (lanes_needed + rt::kThreads - 1) / rt::kThreads;
+  const uint32_t threads = (uint32_t)rt::trace_threads(multi, accel);
+  const uint64_t blocks_needed = (lanes_needed + threads - 1) / threads;
   if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
   if (blocks < 1) blocks = 1;
 
@@ -363,7 +364,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   slot->last.rays_per_lane = paths_per_lane;
   slot->last.slices = p.slices;
   slot->last.workgroups = (uint32_t)blocks;
-  slot->last.threads_per_workgroup = rt::kThreads;
+  slot->last.threads_per_workgroup = threads;
   // multiplied by rays in rt_get_stats; a traversal does not count its tests
   slot->last.sphere_tests = accel ? 0 : scene->dev.n_spheres;
   return RT_OK;

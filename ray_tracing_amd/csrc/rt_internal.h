@@ -14,8 +14,17 @@ constexpr int kWave = 64;
 #ifndef RT_THREADS
 #define RT_THREADS 512
 #endif
-constexpr int kThreads = RT_THREADS;    // 8 waves per workgroup
-constexpr int kWavesPerWg = kThreads / kWave;
+constexpr int kThreads = RT_THREADS;    // 8 waves per workgroup: chunked scan, hierarchy, hooks
+#ifndef RT_THREADS_SINGLE
+#define RT_THREADS_SINGLE 256
+#endif
+// Workgroup of the scan over an LDS-resident sphere list.  A workgroup gives its registers and
+// LDS back only when its last wave ends, so four waves instead of eight let the next launch on
+// another stream move in sooner while this one drains (same speed for a launch on its own).
+constexpr int kThreadsSingle = RT_THREADS_SINGLE;
+constexpr int trace_threads(bool multi, bool accel) {
+  return (multi || accel) ? kThreads : kThreadsSingle;
+}
 #ifndef RT_RAYS_PER_LANE
 #define RT_RAYS_PER_LANE 2
 #endif

@@ -303,7 +303,7 @@ __host__ __device__ constexpr uint32_t lds_capacity(uint32_t n_spheres) {
 // Workgroup-cooperative copy of spheres [base, base+cn) into LDS.
 __device__ __forceinline__ void stage_chunk(const SceneDev& sc, uint32_t base, uint32_t cn,
                                             float4* sph, float* sr2) {
-  for (uint32_t i = threadIdx.x; i < cn; i += kThreads) {
+  for (uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
     sph[i] = sc.trig[base + i];
     sr2[i] = sc.geom[base + i].w;
   }
@@ -843,7 +843,7 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 #define RT_ACCEL_MIN_WAVES 8
 #endif
 template <bool STRICT, bool MULTI, bool ACCEL = false>
-__global__ __launch_bounds__(kThreads, ACCEL ? RT_ACCEL_MIN_WAVES : RT_MIN_WAVES)
+__global__ __launch_bounds__(trace_threads(MULTI, ACCEL), ACCEL ? RT_ACCEL_MIN_WAVES : RT_MIN_WAVES)
 void trace_kernel(const TraceParams p) {
   constexpr int RP = ACCEL ? 1 : R;   // paths per lane
   extern __shared__ float4 lds[];
@@ -1181,7 +1181,9 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   p.out[i] = out;
 }
 
-constexpr size_t kQueueBytes = (size_t)kWavesPerWg * R * Q * kWave * sizeof(uint16_t);
+constexpr size_t queue_bytes(int threads) {
+  return (size_t)threads * R * Q * sizeof(uint16_t);
+}
 
 }  // namespace
 
@@ -1196,14 +1198,16 @@ size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint3
     if (bvh_in_lds) *bvh_in_lds = fits;
     return fits ? stacks + copy : stacks;
   }
-  return (size_t)lds_capacity(n_spheres) * (sizeof(float4) + sizeof(float)) + kQueueBytes;
+  return (size_t)lds_capacity(n_spheres) * (sizeof(float4) + sizeof(float)) +
+         queue_bytes(trace_threads(n_spheres > kChunkSpheres, false));
 }
 
 uint32_t bvh_stack_depth() { return kBvhStack; }
 
 template <bool STRICT, bool MULTI>
 static hipError_t occupancy(size_t lds, int* out) {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, trace_kernel<STRICT, MULTI>, kThreads, lds);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, trace_kernel<STRICT, MULTI>,
+                                                      trace_threads(MULTI, false), lds);
 }
 
 hipError_t trace_max_blocks_per_cu(bool strict, bool multi, bool accel, size_t lds, int* out) {
@@ -1219,7 +1223,7 @@ hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, int block
   const bool multi = p.scene.n_spheres > kChunkSpheres;
   const size_t lds = trace_lds_bytes(p.scene.n_spheres, accel, p.scene.bvh_info.n_nodes,
                                      p.bvh_stack, nullptr);
-  const dim3 grid(blocks), block(kThreads);
+  const dim3 grid(blocks), block(trace_threads(multi, accel));
   if (accel) {
     hipLaunchKernelGGL((trace_kernel<false, false, true>), grid, block, lds, stream, p);
   } else if (strict) {
@@ -1250,7 +1254,8 @@ hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream) {
 
 hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream) {
   if (p.n_rays == 0) return hipSuccess;
-  const size_t lds = (size_t)lds_capacity(kChunkSpheres) * (sizeof(float4) + sizeof(float)) + kQueueBytes;
+  const size_t lds = (size_t)lds_capacity(kChunkSpheres) * (sizeof(float4) + sizeof(float)) +
+                     queue_bytes(kThreads);
   const dim3 grid((p.n_rays + kThreads - 1) / kThreads), block(kThreads);
   if (strict) hipLaunchKernelGGL((hook_kernel<true>), grid, block, lds, stream, p);
   else hipLaunchKernelGGL((hook_kernel<false>), grid, block, lds, stream, p);
