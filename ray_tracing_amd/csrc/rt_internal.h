@@ -22,8 +22,12 @@ constexpr int kThreads = RT_THREADS;    // 8 waves per workgroup: chunked scan, 
 // LDS back only when its last wave ends, so four waves instead of eight let the next launch on
 // another stream move in sooner while this one drains (same speed for a launch on its own).
 constexpr int kThreadsSingle = RT_THREADS_SINGLE;
+#ifndef RT_THREADS_ACCEL
+#define RT_THREADS_ACCEL 512
+#endif
+constexpr int kThreadsAccel = RT_THREADS_ACCEL;   // workgroup of the hierarchy traversal
 constexpr int trace_threads(bool multi, bool accel) {
-  return (multi || accel) ? kThreads : kThreadsSingle;
+  return accel ? kThreadsAccel : multi ? kThreads : kThreadsSingle;
 }
 #ifndef RT_RAYS_PER_LANE
 #define RT_RAYS_PER_LANE 2

@@ -629,7 +629,7 @@ __device__ __forceinline__ uint32_t bvh_load1(const uint32_t* p) {
   return *p;
 }
 
-// `stack` is this thread's column of a [kBvhStack][kThreads] LDS array.
+// `stack` is this thread's column of a [kBvhStack][kThreadsAccel] LDS array.
 template <bool IN_LDS>
 __device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, const BvhSource& src,
                                         uint32_t* stack, uint32_t& n_interior, uint32_t& n_tests) {
@@ -663,17 +663,17 @@ __device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, const BvhSo
     // tested at all: its children's are)
     uint32_t a = __float_as_uint(bvh_load4<IN_LDS>(nodes).w);
     uint32_t b = __float_as_uint(bvh_load4<IN_LDS>(nodes + 1).w);
-    for (;;) {
-      bool pop = true;
-      if (b & kBvhLeaf) {
-        const uint32_t count = b & ~kBvhLeaf;
-#ifdef RT_DIAG_PHASES
-        n_tests += count;
-#endif
-        for (uint32_t k = 0; k < count; ++k)
-          candidate_hit(bvh_load4<IN_LDS>(src.leaf_geom + a + k),
-                        bvh_load1<IN_LDS>(src.leaf_index + a + k), o, d, P.a, rb, closest, best);
-      } else {
+    // Two nested loops rather than one that takes either kind of node: the lanes of a wave first
+    // all walk down to a leaf (those that arrive early wait), then test their leaves together,
+    // so a wave pays for the sphere tests once per leaf round and not once per node.
+    const auto pop = [&]() {
+      sp--;
+      const uint32_t* words = reinterpret_cast<const uint32_t*>(nodes + 2 * stack[sp * kThreadsAccel]);
+      a = bvh_load1<IN_LDS>(words + 3);
+      b = bvh_load1<IN_LDS>(words + 7);
+    };
+    for (bool live = true; live;) {
+      while (!(b & kBvhLeaf)) {
 #ifdef RT_DIAG_PHASES
         n_interior++;
 #endif
@@ -685,21 +685,28 @@ __device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, const BvhSo
         if (hl || hr) {
           const bool left = hl && (!hr || !(tr < tl));
           if (hl && hr) {
-            stack[sp * kThreads] = left ? b : a;   // the farther child waits
+            stack[sp * kThreadsAccel] = left ? b : a;   // the farther child waits
             sp++;
           }
           a = __float_as_uint(left ? l0.w : r0.w);
           b = __float_as_uint(left ? l1.w : r1.w);
-          pop = false;
+        } else if (sp == 0) {
+          live = false;
+          break;
+        } else {
+          pop();
         }
       }
-      if (pop) {
-        if (sp == 0) break;
-        sp--;
-        const uint32_t node = stack[sp * kThreads];
-        a = __float_as_uint(bvh_load4<IN_LDS>(nodes + 2 * node).w);
-        b = __float_as_uint(bvh_load4<IN_LDS>(nodes + 2 * node + 1).w);
-      }
+      if (!live) break;
+      const uint32_t count = b & ~kBvhLeaf;
+#ifdef RT_DIAG_PHASES
+      n_tests += count;
+#endif
+      for (uint32_t k = 0; k < count; ++k)
+        candidate_hit(bvh_load4<IN_LDS>(src.leaf_geom + a + k),
+                      bvh_load1<IN_LDS>(src.leaf_index + a + k), o, d, P.a, rb, closest, best);
+      if (sp == 0) break;
+      pop();
     }
   }
   P.closest = closest;
@@ -842,6 +849,9 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 #ifndef RT_ACCEL_MIN_WAVES
 #define RT_ACCEL_MIN_WAVES 8
 #endif
+#ifndef RT_ACCEL_WAVES
+#define RT_ACCEL_WAVES RT_ACCEL_MIN_WAVES   // waves per SIMD the traversal kernel runs at
+#endif
 template <bool STRICT, bool MULTI, bool ACCEL = false>
 __global__ __launch_bounds__(trace_threads(MULTI, ACCEL), ACCEL ? RT_ACCEL_MIN_WAVES : RT_MIN_WAVES)
 void trace_kernel(const TraceParams p) {
@@ -868,12 +878,12 @@ void trace_kernel(const TraceParams p) {
   bvh_src.leaf_geom = p.scene.leaf_geom;
   bvh_src.leaf_index = p.scene.leaf_index;
   if (ACCEL && p.bvh_in_lds) {
-    float4* nodes_lds = lds + p.bvh_stack * kThreads / 4;
+    float4* nodes_lds = lds + p.bvh_stack * kThreadsAccel / 4;
     float4* geom_lds = nodes_lds + 2 * p.scene.bvh_info.n_nodes;
     uint32_t* index_lds = reinterpret_cast<uint32_t*>(geom_lds + n);
-    for (uint32_t i = threadIdx.x; i < 2 * p.scene.bvh_info.n_nodes; i += kThreads)
+    for (uint32_t i = threadIdx.x; i < 2 * p.scene.bvh_info.n_nodes; i += kThreadsAccel)
       nodes_lds[i] = bvh_src.nodes[i];
-    for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
+    for (uint32_t i = threadIdx.x; i < n; i += kThreadsAccel) {
       geom_lds[i] = p.scene.leaf_geom[i];
       index_lds[i] = p.scene.leaf_index[i];
     }
@@ -1190,11 +1200,13 @@ constexpr size_t queue_bytes(int threads) {
 size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint32_t bvh_depth,
                        bool* bvh_in_lds) {
   if (accel) {
-    // one stack row per level of the tree (at least one), four workgroups per CU
-    const size_t stacks = (size_t)(bvh_depth ? bvh_depth : 1) * kThreads * sizeof(uint32_t);
+    // one stack row per level of the tree (at least one); the copy of the hierarchy goes in
+    // when the workgroups that fill a CU's wave slots still all fit into its LDS
+    const size_t stacks = (size_t)(bvh_depth ? bvh_depth : 1) * kThreadsAccel * sizeof(uint32_t);
     const size_t copy = (size_t)bvh_nodes * sizeof(BvhNode) +
                         (size_t)n_spheres * (sizeof(float4) + sizeof(uint32_t));
-    const bool fits = stacks + copy <= kLdsPerWorkgroup / 2;
+    constexpr size_t wgs_per_cu = (size_t)RT_ACCEL_WAVES * 4 * kWave / kThreadsAccel;
+    const bool fits = stacks + copy <= 160 * 1024 / wgs_per_cu;
     if (bvh_in_lds) *bvh_in_lds = fits;
     return fits ? stacks + copy : stacks;
   }
@@ -1213,7 +1225,7 @@ static hipError_t occupancy(size_t lds, int* out) {
 hipError_t trace_max_blocks_per_cu(bool strict, bool multi, bool accel, size_t lds, int* out) {
   if (accel)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, trace_kernel<false, false, true>,
-                                                        kThreads, lds);
+                                                        kThreadsAccel, lds);
   if (strict) return multi ? occupancy<true, true>(lds, out) : occupancy<true, false>(lds, out);
   return multi ? occupancy<false, true>(lds, out) : occupancy<false, false>(lds, out);
 }
