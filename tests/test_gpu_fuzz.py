@@ -1,0 +1,123 @@
+"""Adversarial per-ray comparison: scenes and rays chosen to make the discriminant noisy
+(silhouette rays, origins on and inside spheres, directions of every length, scenes far from the
+origin, radii over five decades).  Three ways to find the closest hit must agree bit for bit -
+the literal arithmetic (STRICT_FP), the conservative scan in front of it (default) and the
+hierarchy (ACCEL) - and the literal one must equal the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ray_tracing_amd import abi, hip
+
+pytestmark = pytest.mark.gpu
+
+STRICT = abi.RT_FLAG_STRICT_FP
+ACCEL = abi.RT_FLAG_ACCEL
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    hip.init(0)
+    yield
+
+
+def random_scene(rs, n, centre, spread, r_lo, r_hi):
+    mats = []
+    for _ in range(12):
+        kind = rs.integers(0, 3)
+        col = rs.uniform(0.05, 0.95, size=3)
+        mats.append((*col, int(kind == 1), float(rs.uniform(0, 1)), int(kind == 2),
+                     float(rs.uniform(1.1, 2.0))))
+    m = O.materials_array(mats)
+    c = np.asarray(centre, dtype=np.float64) + rs.uniform(-spread, spread, size=(n, 3))
+    r = np.exp(rs.uniform(np.log(r_lo), np.log(r_hi), size=n))
+    s = O.spheres_array([(c[i, 0], c[i, 1], c[i, 2], r[i], int(rs.integers(0, len(mats))))
+                         for i in range(n)])
+    return s, m
+
+
+def unit(v):
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def adversarial_rays(rs, s, n_each):
+    c_all = np.stack([s["x"], s["y"], s["z"]], axis=1).astype(np.float64)
+    r_all = s["radius"].astype(np.float64)
+    spread = np.abs(c_all - c_all.mean(axis=0)).max() + r_all.max()
+    parts = []
+
+    def pick():
+        i = rs.integers(0, len(s), size=n_each)
+        return c_all[i], r_all[i]
+
+    # silhouette rays, a hair inside or outside, from near and far
+    c, r = pick()
+    away = unit(rs.normal(size=(n_each, 3)))
+    org = c + away * (r * (1.0 + 10.0 ** rs.uniform(-2, 3, n_each)))[:, None]
+    t = rs.normal(size=(n_each, 3))
+    t = unit(t - (t * away).sum(axis=1, keepdims=True) * away)
+    nudge = 1.0 + rs.choice([-1, 1], size=n_each) * 10.0 ** rs.uniform(-7, -2, n_each)
+    parts.append((org, c + t * (r * nudge)[:, None] - org))
+    # origins on a surface (as after a bounce), leaving, entering and along the tangent plane
+    c, r = pick()
+    nrm = unit(rs.normal(size=(n_each, 3)))
+    org = c + nrm * r[:, None]
+    tang = rs.normal(size=(n_each, 3))
+    tang = unit(tang - (tang * nrm).sum(axis=1, keepdims=True) * nrm)
+    lift = rs.choice([-1, 1], size=n_each) * 10.0 ** rs.uniform(-7, 0, n_each)
+    parts.append((org, tang + nrm * lift[:, None]))
+    # origins inside a sphere
+    c, r = pick()
+    org = c + unit(rs.normal(size=(n_each, 3))) * (r * rs.uniform(0, 0.999, n_each))[:, None]
+    parts.append((org, rs.normal(size=(n_each, 3))))
+    # from outside the scene towards it
+    org = c_all.mean(axis=0) + unit(rs.normal(size=(n_each, 3))) * spread * rs.uniform(2, 50, (n_each, 1))
+    tgt = c_all[rs.integers(0, len(s), size=n_each)] + rs.normal(size=(n_each, 3)) * r_all.mean()
+    parts.append((org, tgt - org))
+
+    org = np.concatenate([p[0] for p in parts])
+    d = np.concatenate([p[1] for p in parts])
+    d = unit(d) * 10.0 ** rs.uniform(-3, 3, size=(len(d), 1))    # directions of every length
+    rays = np.zeros(len(org), dtype=abi.RAY_IN_DTYPE)
+    rays["ox"], rays["oy"], rays["oz"] = org.astype(np.float32).T
+    rays["dx"], rays["dy"], rays["dz"] = d.astype(np.float32).T
+    return rays
+
+
+def assert_same(a, b, nan_equal=False):
+    for f in a.dtype.names:
+        x, y = a[f], b[f]
+        if x.dtype.kind != "f":
+            assert np.array_equal(x, y), f
+            continue
+        same = x.view(np.uint32) == y.view(np.uint32)
+        if nan_equal:   # a NaN's sign and payload differ between the CPU and the GPU
+            same |= np.isnan(x) & np.isnan(y)
+        assert same.all(), (f, int((~same).sum()), int(np.flatnonzero(~same)[0]))
+
+
+SCENES = [
+    # n, centre, spread, r_lo, r_hi, checked against the oracle too
+    (300, (0, 0, 0), 10.0, 0.01, 2.0, True),
+    (300, (0, 0, 0), 1000.0, 0.001, 100.0, True),
+    (200, (1e4, 1e4, -1e4), 50.0, 0.1, 5.0, True),       # f32 spacing of 1e-3 at the centres
+    (300, (3, -2, 1), 2.0, 0.2, 1.5, True),              # heavily overlapping spheres
+    (2600, (0, 0, 0), 50.0, 0.05, 1.0, False),           # more spheres than one LDS chunk holds
+]
+
+
+@pytest.mark.parametrize("case", range(len(SCENES)))
+def test_three_ways_to_the_closest_hit_agree(case):
+    n, centre, spread, r_lo, r_hi, with_oracle = SCENES[case]
+    rs = np.random.default_rng(100 + case)
+    s, m = random_scene(rs, n, centre, spread, r_lo, r_hi)
+    rays = adversarial_rays(rs, s, 1500)
+    scene = hip.Scene(s, m)
+    strict = hip.trace_rays(scene, rays, seed=5, flags=STRICT)
+    assert_same(hip.trace_rays(scene, rays, seed=5, flags=0), strict)
+    assert_same(hip.trace_rays(scene, rays, seed=5, flags=ACCEL), strict)
+    scene.close()
+    assert strict["hit"].sum() > 0.2 * len(rays)
+    if with_oracle:
+        ref = O.bounce(O.make_world(s, m), rays, seed=5, pow5_mode=O.RO_POW5_MUL)
+        assert_same(strict, ref, nan_equal=True)
