@@ -121,3 +121,23 @@ def test_three_ways_to_the_closest_hit_agree(case):
     if with_oracle:
         ref = O.bounce(O.make_world(s, m), rays, seed=5, pow5_mode=O.RO_POW5_MUL)
         assert_same(strict, ref, nan_equal=True)
+
+
+@pytest.mark.parametrize("flags", [0, STRICT, ACCEL])
+def test_image_sums_on_a_random_overlapping_scene(flags):
+    """Whole paths (max_depth 50) through a scene of random materials and overlapping spheres of
+    very different sizes: per-pixel sums in the reference's sample order equal the oracle's."""
+    rs = np.random.default_rng(42)
+    s, m = random_scene(rs, 150, (0, 0.5, 0), 4.0, 0.05, 3.0)
+    w, h, spp = 64, 36, 6
+    cam = O.camera_new((13, 2, 3), (0, 0, 0), 30.0, w / h)
+    tiles = O.job_queue(w, h, 64, 64)
+    _, _, ctr, ref = O.render(s, m, cam, w, h, spp, 50, 9, mode=O.RO_MODE_ITER_MUL, threads=8,
+                              tiles=tiles, want_sums=True)
+    got = hip.render_tiles(s, m, cam, w, h, spp, 50, 9, tiles,
+                           flags=flags | abi.RT_FLAG_SEQUENTIAL_SUM)
+    same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all()
+    st = hip.get_stats()
+    assert st.rays == ctr.rays and st.samples == ctr.samples
+    assert ctr.rays > 3 * ctr.samples      # paths do bounce around in there
