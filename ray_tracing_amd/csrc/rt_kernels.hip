@@ -62,6 +62,14 @@
 namespace rt {
 namespace {
 
+// Wave priority by phase.  Refill, replay and shading are chains of dependent instructions; at
+// equal priority each of them waits its turn behind the other waves' scan loops, which always
+// have an instruction ready.  Letting those chains go first shortens them and leaves the scan
+// the same issue slots (-0.8 % kernel time on the benchmark frame, -1.1 % on the glass scene;
+// the opposite assignment costs +2.8 %).
+#define RT_PRIO_SCAN() __builtin_amdgcn_s_setprio(0)
+#define RT_PRIO_REST() __builtin_amdgcn_s_setprio(3)
+
 struct PhaseClock {
   unsigned long long t0, refill, scan, replay, shade, steps;
   unsigned long long t_start, t_exhausted, tail_steps;
@@ -471,6 +479,7 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
   uint32_t i = 0;
   while (i < cn) {
     bool flush = false;
+    RT_PRIO_SCAN();
     // The records of the next block are read from LDS while the current one is evaluated,
     // so the read latency is off the critical path: two register sets, A and B, alternate
     // (the loop body is two blocks long so that no set is ever copied).  The buffer is padded
@@ -510,6 +519,7 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
       }
     }
     RT_STAMP(clk.scan, clk.t0);
+    RT_PRIO_REST();
     replay_queue(P, sph, sr2, chunk_base, q, lane);
     RT_STAMP(clk.replay, clk.t0);
   }
