@@ -428,6 +428,59 @@ __global__ void k_cons_ahead(const float4* __restrict__ spheres, int n, int reps
   out[tid] = (float)cnt;
 }
 
+
+// ---- 7. sphere records through the scalar cache instead of LDS: the records are wave-uniform,
+// so they can live in SGPRs (read-ahead included) and leave the vector registers to the paths.
+// One SGPR operand per instruction: the per-sphere constant joins in its own fma.
+template <int R>
+__global__ void k_cons_smem(const float4* __restrict__ spheres, int n, int reps, float* out) {
+  typedef float cf4 __attribute__((ext_vector_type(4)));
+  const __attribute__((address_space(4))) cf4* sp =
+      (const __attribute__((address_space(4))) cf4*)spheres;
+  float ox[R], oy[R], oz[R], nx[R], ny[R], nz[R], od[R], hnoo[R];
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned h = (tid * R + r) * 2654435761u;
+    ox[r] = 13.f + (h & 255) * 1e-3f; oy[r] = 2.f + ((h >> 8) & 255) * 1e-3f; oz[r] = 3.f + (h & 7) * 1e-3f;
+    nx[r] = 0.96f - ((h >> 16) & 255) * 1e-3f; ny[r] = 0.15f + (h & 3) * 1e-3f; nz[r] = 0.22f - (h >> 24) * 1e-3f;
+    od[r] = -(ox[r] * nx[r] + oy[r] * ny[r] + oz[r] * nz[r]);
+    hnoo[r] = -0.5f * (ox[r] * ox[r] + oy[r] * oy[r] + oz[r] * oz[r]);
+  }
+  int cnt = 0;
+  auto block = [&](const cf4 (&s)[4]) {
+    int m = (int)0x80000000;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float hb = __builtin_fmaf(s[u].z, nz[r], __builtin_fmaf(s[u].y, ny[r], __builtin_fmaf(s[u].x, nx[r], od[r])));
+        float t = __builtin_fmaf(s[u].z, oz[r], __builtin_fmaf(s[u].y, oy[r], __builtin_fmaf(s[u].x, ox[r], hnoo[r])));
+        float disc = __builtin_fmaf(hb, hb, __builtin_fmaf(t, 2.0f, s[u].w));
+        m = max(m, __float_as_int(disc));
+      }
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= 0) != 0, 0)) cnt += (m >= 0);
+  };
+  for (int rep = 0; rep < reps; ++rep) {
+    cf4 A[4], B[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) A[u] = sp[u];
+    for (int i = 0; i + 8 <= n; i += 8) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) B[u] = sp[i + 4 + u];
+      __builtin_amdgcn_sched_barrier(0);
+      block(A);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) A[u] = sp[i + 8 + u];
+      __builtin_amdgcn_sched_barrier(0);
+      block(B);
+    }
+    ox[0] += 1e-6f;
+  }
+  out[tid] = (float)cnt;
+}
+
 static float time_ms(hipEvent_t e0, hipEvent_t e1) { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
 
 int main(int argc, char** argv) {
@@ -511,7 +564,8 @@ int main(int argc, char** argv) {
     const int n = 488, reps = 400;
     std::vector<float4> hs(n);
     for (int i = 0; i < n; ++i) hs[i] = make_float4((i % 22) - 11 + 0.3f, 0.2f, (i / 22) - 11 + 0.4f, -1e6f);
-    float4* ds; CK(hipMalloc(&ds, sizeof(float4) * n));
+    float4* ds; CK(hipMalloc(&ds, sizeof(float4) * (n + 8)));   // padded for the read-ahead
+    CK(hipMemset(ds, 0, sizeof(float4) * (n + 8)));
     CK(hipMemcpy(ds, hs.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     auto run = [&](const char* name, auto kern, int R, int wps, int threads) {
       int blocks = cus * wps * 256 / threads;
@@ -528,6 +582,13 @@ int main(int argc, char** argv) {
       printf("%-14s paths/lane %d waves/SIMD %d : %8.3f ms  %7.2f Gtests/s  = %5.1f%% of 157.3 TF at 17 flop/test\n",
              name, R, wps, best, tests / best * 1e-6, tests * 17 / best * 1e-9 / 157.3 * 100);
     };
+    if (argc > 3 && !strcmp(argv[3], "smem")) {
+      for (int wps : {4, 5, 6, 8}) {
+        run("ahead(lds)", (k_cons_ahead<2, false>), 2, wps, 256);
+        run("smem", (k_cons_smem<2>), 2, wps, 256);
+      }
+      return 0;
+    }
     for (int wps : {2, 4, 8}) {
       run("ahead", (k_cons_ahead<2, false>), 2, wps, 256);
       run("ahead_pk", (k_cons_ahead<2, true>), 2, wps, 256);
