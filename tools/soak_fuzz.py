@@ -1,6 +1,8 @@
 """Developer soak run of tests/test_gpu_fuzz.py's comparison over many random scenes: the literal
 arithmetic (STRICT_FP), the conservative scan and the hierarchy must give the same per-ray bits.
-Usage: python tools/soak_fuzz.py [n_scenes] [rays_per_kind] [first_seed]"""
+Usage: python tools/soak_fuzz.py [n_scenes] [rays_per_kind] [first_seed]
+       python tools/soak_fuzz.py images [n_scenes] [first_seed]   whole paths: per-pixel sums of
+           small frames (reference sample order, max_depth 50) in the three modes"""
 import os
 import sys
 import time
@@ -16,7 +18,49 @@ import test_gpu_fuzz as F  # noqa: E402
 from ray_tracing_amd import abi, hip  # noqa: E402
 
 
+def images():
+    import oracle_lib as O
+    n_scenes = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    hip.init(0)
+    seq = abi.RT_FLAG_SEQUENTIAL_SUM
+    t0 = time.time()
+    rays = 0
+    for k in range(n_scenes):
+        rs = np.random.default_rng(seed0 + k)
+        n = int(rs.choice([3, 40, 150, 600, 2300]))
+        r_hi = float(10.0 ** rs.uniform(-0.7, 0.6))
+        s, m = F.random_scene(rs, n, (0, 0.5, 0), float(rs.uniform(1.5, 8.0)), r_hi * 0.02, r_hi)
+        w, h = int(rs.integers(17, 90)), int(rs.integers(9, 50))
+        spp = int(rs.integers(1, 9))
+        cam = O.camera_new((13, 2, 3), (0, 0, 0), float(rs.uniform(15, 60)), w / h)
+        tiles = O.job_queue(w, h, 64, 64)
+        ref = hip.render_tiles(s, m, cam, w, h, spp, 50, k, tiles, flags=seq | abi.RT_FLAG_STRICT_FP)
+        ref_rays = hip.get_stats().rays
+        if k % 4 == 0:   # and the literal arithmetic against the CPU oracle
+            _, _, ctr, want = O.render(s, m, cam, w, h, spp, 50, k, mode=O.RO_MODE_ITER_MUL,
+                                       threads=16, tiles=tiles, want_sums=True)
+            same = (want.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(want) & np.isnan(ref))
+            if not same.all() or ctr.rays != ref_rays:
+                print("ORACLE MISMATCH scene seed %d n %d %dx%d spp %d: %d values differ"
+                      % (seed0 + k, n, w, h, spp, int((~same).sum())), flush=True)
+                sys.exit(1)
+        for flags in (0, abi.RT_FLAG_ACCEL):
+            got = hip.render_tiles(s, m, cam, w, h, spp, 50, k, tiles, flags=seq | flags)
+            same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+            if not same.all() or hip.get_stats().rays != ref_rays:
+                print("MISMATCH scene seed %d flags %d n %d %dx%d spp %d: %d values differ"
+                      % (seed0 + k, flags, n, w, h, spp, int((~same).sum())), flush=True)
+                sys.exit(1)
+        rays += ref_rays
+        if k % 20 == 19:
+            print("%d scenes, %d rays, %.0f s" % (k + 1, rays, time.time() - t0), flush=True)
+    print("all equal: %d scenes, %d rays" % (n_scenes, rays))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "images":
+        return images()
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     n_each = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
