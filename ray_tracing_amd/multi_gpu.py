@@ -72,10 +72,15 @@ class ShardedFrame:
                                  device=device)
         self.tiles, self.offsets, self.strides = plan.tiles_for(rank)
         if rank == 0:
-            like = self.local.cpu() if stage_through_host else self.local
-            self.gathered = [torch.zeros_like(like) for _ in range(plan.world_size)]
+            # the gather writes straight into the slices of one buffer, which is already the
+            # concatenation of the ranks' compact buffers that row_map indexes
+            self.stacked = torch.zeros((plan.world_size,) + tuple(self.local.shape),
+                                       dtype=torch.float32,
+                                       device="cpu" if stage_through_host else device)
+            self.gathered = list(self.stacked.unbind(0))
             self.row_map = torch.from_numpy(plan.frame_row_map()).to(device)
         else:
+            self.stacked = None
             self.gathered = None
             self.row_map = None
 
@@ -93,12 +98,12 @@ class ShardedFrame:
             dist.gather(self.local.cpu(), self.gathered, dst=0)   # .cpu() waits for the render
             if self.rank != 0:
                 return None
-            stacked = torch.stack(self.gathered, dim=0).to(self.local.device)
+            stacked = self.stacked.to(self.local.device)
         else:
             dist.gather(self.local, self.gathered, dst=0)
             if self.rank != 0:
                 return None
-            stacked = torch.stack(self.gathered, dim=0)
+            stacked = self.stacked
         flat = stacked.reshape(-1, self.plan.width, 3)
         return flat.index_select(0, self.row_map)
 

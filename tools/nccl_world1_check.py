@@ -37,9 +37,9 @@ for k in range(4):
 
         if len(sharded.tiles):
             render_fn(sharded.tiles, sharded.offsets, sharded.strides, sharded.local)
-        gathered = [torch.zeros_like(sharded.local)]
-        dist.gather(sharded.local, gathered, dst=0)           # the call bench.py makes, N = 1
-        frames.append(torch.stack(gathered).reshape(-1, W, 3).index_select(0, sharded.row_map))
+        # the call bench.py makes, N = 1: gather into the slices of ShardedFrame's one buffer
+        dist.gather(sharded.local, sharded.gathered, dst=0)
+        frames.append(sharded.stacked.reshape(-1, W, 3).index_select(0, sharded.row_map))
 dist.barrier()
 torch.cuda.synchronize()
 t = torch.tensor([1.5], dtype=torch.float64, device=device)
