@@ -4,7 +4,10 @@ on every rank) and prints kernel time, wall time per step and the scaling that w
 every rank took that long.
 With frames_in_flight > 1 consecutive frames go to alternating streams, like bench.py does on
 several GPUs, so that one frame's drain overlaps the next frame's start.
-Usage: python tools/rank_share_bench.py [rank] [spp] [reps] [frames_in_flight]"""
+With follow_up = 1 every frame is followed, on its stream, by a small torch kernel over its
+buffer: a stand-in for the gather's kernel, which like it needs a place on the GPU while the
+other stream's persistent kernel fills it.
+Usage: python tools/rank_share_bench.py [rank] [spp] [reps] [frames_in_flight] [follow_up]"""
 import os
 import sys
 import time
@@ -22,6 +25,7 @@ def main():
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     flight = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    follow_up = len(sys.argv) > 5 and sys.argv[5] == "1"
     W, H = 1920, 1080
     hip.init(0)
     world = host.create_random_world(1, (-11, 11))
@@ -41,9 +45,13 @@ def main():
                                     streams[k].cuda_stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        copies = [torch.empty_like(o) for o in outs]
         for k in range(reps):
             hip.render_device_async(scene, frame, tiles, offs, strides, True,
                                     outs[k % flight].data_ptr(), streams[k % flight].cuda_stream)
+            if follow_up:
+                with torch.cuda.stream(streams[k % flight]):
+                    copies[k % flight].copy_(outs[k % flight])
         torch.cuda.synchronize()
         for k in range(1, flight):
             assert torch.equal(outs[0].view(torch.int32), outs[k].view(torch.int32))
