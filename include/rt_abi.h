@@ -268,7 +268,8 @@ int rt_get_launch_ms(uint32_t n_last, float* out_ms);
  * drain, longest-lived wave} and out16[8..13] = {drain steps that scanned (sum over waves),
  * drain steps in tail mode (sum), most scanning drain steps of one wave, most tail-mode steps of
  * one wave, cycles inside tail mode (sum), waves} and out16[14..15] = {interior nodes opened,
- * leaf spheres tested} by RT_FLAG_ACCEL traversals; "drain" is the time after the work queue ran
+ * leaf spheres tested} by RT_FLAG_ACCEL traversals, or without that flag {candidates the scan
+ * queued, 64 x trips of the waves' replay loops}; "drain" is the time after the work queue ran
  * dry.  All zero unless the library was built with -DRT_DIAG_PHASES (a build for reading
  * shares; its stamps slow the kernel down).  No counterpart in the reference. */
 int rt_get_phase_cycles(uint64_t* out16);

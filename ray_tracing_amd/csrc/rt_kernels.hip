@@ -74,6 +74,7 @@ struct PhaseClock {
   unsigned long long t0, refill, scan, replay, shade, steps;
   unsigned long long t_start, t_exhausted, tail_steps;
   unsigned long long drain_scan_steps, tail_cycles;
+  unsigned long long cand, replay_iters;   // queued candidates (per lane), replay loop trips (per wave)
 };
 
 #ifndef RT_MIN_WAVES
@@ -440,7 +441,8 @@ __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&
 }
 
 __device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, const float* sr2,
-                                             uint32_t chunk_base, const uint16_t* q, uint32_t lane) {
+                                             uint32_t chunk_base, const uint16_t* q, uint32_t lane,
+                                             PhaseClock& clk) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const uint32_t n = P[r].cnt;
@@ -458,7 +460,13 @@ __device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, co
       }
     } else {
       ReplayBounds rb = replay_bounds(P[r].closest, P[r].a);
+#ifdef RT_DIAG_PHASES
+      clk.cand += n;
+#endif
       for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0; ++k) {
+#ifdef RT_DIAG_PHASES
+        clk.replay_iters++;
+#endif
         if (k < n) {
           const uint32_t li = q[(r * Q + (n - 1 - k)) * kWave + lane];   // last to first
           float4 rec = sph[li];
@@ -520,7 +528,7 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
     }
     RT_STAMP(clk.scan, clk.t0);
     RT_PRIO_REST();
-    replay_queue(P, sph, sr2, chunk_base, q, lane);
+    replay_queue(P, sph, sr2, chunk_base, q, lane, clk);
     RT_STAMP(clk.replay, clk.t0);
   }
 }
@@ -1059,7 +1067,9 @@ void trace_kernel(const TraceParams p) {
     atomicAdd(&p.counters->phase[13], 1ull);                     // waves
   }
   {
-    const unsigned long long bi = wave_sum(bvh_interior), bt = wave_sum(bvh_tests);
+    // the hierarchy's counts, or (scan) queued candidates and 64 x the replay loop's trips
+    const unsigned long long bi = ACCEL ? wave_sum(bvh_interior) : wave_sum((uint32_t)clk.cand);
+    const unsigned long long bt = ACCEL ? wave_sum(bvh_tests) : clk.replay_iters * 64ull;
     if (lane == 0) {
       atomicAdd(&p.counters->phase[14], bi);                     // hierarchy: interior nodes opened
       atomicAdd(&p.counters->phase[15], bt);                     // hierarchy: leaf spheres tested

@@ -54,9 +54,13 @@ def main():
         waves = st.workgroups * st.threads_per_workgroup / 64
         print("drain after the work queue emptied: mean %.0f kcycles per wave, longest %.0f kcycles; "
               "longest-lived wave %.0f kcycles" % (ph[5] / waves / 1e3, ph[6] / 1e3, ph[7] / 1e3))
-    if ph[14] + ph[15] > 0:
+    if ph[14] + ph[15] > 0 and flags & 4:
         print("hierarchy: %.1f interior nodes opened and %.1f leaf spheres tested per ray"
               % (ph[14] / max(st.rays, 1), ph[15] / max(st.rays, 1)))
+    elif ph[14] + ph[15] > 0:
+        print("replay: %.2f candidates per ray; the wave's replay loop makes %.2f trips per ray "
+              "(%.0f %% of its lanes busy)" % (ph[14] / max(st.rays, 1), ph[15] / max(st.rays, 1),
+                                               100.0 * ph[14] / max(ph[15], 1)))
     img = out.cpu().numpy()
     print("mean rgb", np.nanmean(img, axis=(0, 1)), "nan px", int(np.isnan(img).any(axis=2).sum()))
 
