@@ -481,6 +481,153 @@ __global__ void k_cons_smem(const float4* __restrict__ spheres, int n, int reps,
   out[tid] = (float)cnt;
 }
 
+// ---- 8. the production form with two SPHERES per packed instruction: LDS holds sphere pairs as
+// (x0,x1,y0,y1), (z0,z1,w0,w1); the per-path constants sit duplicated in register pairs, so no
+// operand needs a lane select.  Blocks of two pairs (four spheres), read ahead like the others.
+template <int R>
+__global__ void k_cons_sphere_pairs(const float4* __restrict__ spheres, int n, int reps, float* out) {
+  extern __shared__ float4 lds[];   // 2 float4 per pair
+  for (int i = threadIdx.x; i < (n + 8) / 2; i += blockDim.x) {
+    const float4 a = spheres[2 * i < n ? 2 * i : 0], b = spheres[2 * i + 1 < n ? 2 * i + 1 : 0];
+    lds[2 * i] = make_float4(a.x, b.x, a.y, b.y);
+    lds[2 * i + 1] = make_float4(a.z, b.z, a.w, b.w);
+  }
+  __syncthreads();
+  f2 ox[R], oy[R], oz[R], nx[R], ny[R], nz[R], od[R], noo[R];
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned h = (tid * R + r) * 2654435761u;
+    const float x = 13.f + (h & 255) * 1e-3f, y = 2.f + ((h >> 8) & 255) * 1e-3f, z = 3.f + (h & 7) * 1e-3f;
+    const float a = 0.96f - ((h >> 16) & 255) * 1e-3f, b = 0.15f + (h & 3) * 1e-3f, c = 0.22f - (h >> 24) * 1e-3f;
+    ox[r] = f2{x, x}; oy[r] = f2{y, y}; oz[r] = f2{z, z};
+    nx[r] = f2{a, a}; ny[r] = f2{b, b}; nz[r] = f2{c, c};
+    const float d = -(x * a + y * b + z * c), q = -(x * x + y * y + z * z);
+    od[r] = f2{d, d}; noo[r] = f2{q, q};
+  }
+  int cnt = 0;
+  const f2 two = {2.0f, 2.0f};
+  auto block = [&](const float4 (&s)[4]) {   // s[2p], s[2p+1]: pair p
+    int m = (int)0x80000000;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const f2 sx = {s[2 * p].x, s[2 * p].y}, sy = {s[2 * p].z, s[2 * p].w};
+      const f2 sz = {s[2 * p + 1].x, s[2 * p + 1].y}, sw = {s[2 * p + 1].z, s[2 * p + 1].w};
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        f2 hb = __builtin_elementwise_fma(sz, nz[r], __builtin_elementwise_fma(sy, ny[r],
+                __builtin_elementwise_fma(sx, nx[r], od[r])));
+        f2 qh = __builtin_elementwise_fma(sz, oz[r], __builtin_elementwise_fma(sy, oy[r],
+                __builtin_elementwise_fma(sx, ox[r], sw)));
+        f2 disc = __builtin_elementwise_fma(hb, hb, __builtin_elementwise_fma(qh, two, noo[r]));
+        m = max(m, max(__float_as_int(disc.x), __float_as_int(disc.y)));
+      }
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= 0) != 0, 0)) cnt += (m >= 0);
+  };
+  for (int rep = 0; rep < reps; ++rep) {
+    float4 A[4], B[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) A[u] = lds[u];
+    for (int i = 0; i + 8 <= n; i += 8) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) B[u] = lds[i + 4 + u];
+      __builtin_amdgcn_sched_barrier(0);
+      block(A);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) A[u] = lds[i + 8 + u];
+      __builtin_amdgcn_sched_barrier(0);
+      block(B);
+    }
+    ox[0] += 1e-6f;
+  }
+  out[tid] = (float)cnt;
+}
+
+// ---- 9. sphere records from LDS and from the scalar cache side by side: a ds_read_b128 costs
+// the LDS pipe 8 cycles however many lanes share its address, and at two paths per lane that
+// pipe is as busy as the vector ALU, so every NTH block of four spheres comes through SGPRs.
+template <int R, int LDS_BLOCKS>
+__global__ void k_cons_mixed(const float4* __restrict__ spheres, int n, int reps, float* out) {
+  typedef float cf4 __attribute__((ext_vector_type(4)));
+  const __attribute__((address_space(4))) cf4* sp =
+      (const __attribute__((address_space(4))) cf4*)spheres;
+  extern __shared__ float4 lds[];
+  for (int i = threadIdx.x; i < n + 8; i += blockDim.x) lds[i] = spheres[i < n ? i : 0];
+  __syncthreads();
+  float ox[R], oy[R], oz[R], nx[R], ny[R], nz[R], od[R], noo[R], hnoo[R];
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned h = (tid * R + r) * 2654435761u;
+    ox[r] = 13.f + (h & 255) * 1e-3f; oy[r] = 2.f + ((h >> 8) & 255) * 1e-3f; oz[r] = 3.f + (h & 7) * 1e-3f;
+    nx[r] = 0.96f - ((h >> 16) & 255) * 1e-3f; ny[r] = 0.15f + (h & 3) * 1e-3f; nz[r] = 0.22f - (h >> 24) * 1e-3f;
+    od[r] = -(ox[r] * nx[r] + oy[r] * ny[r] + oz[r] * nz[r]);
+    noo[r] = -(ox[r] * ox[r] + oy[r] * oy[r] + oz[r] * oz[r]);
+    hnoo[r] = 0.5f * noo[r];
+  }
+  int cnt = 0;
+  auto block_v = [&](const float4 (&s)[4]) {
+    int m = (int)0x80000000;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float hb = __builtin_fmaf(s[u].z, nz[r], __builtin_fmaf(s[u].y, ny[r], __builtin_fmaf(s[u].x, nx[r], od[r])));
+        float qh = __builtin_fmaf(s[u].z, oz[r], __builtin_fmaf(s[u].y, oy[r], __builtin_fmaf(s[u].x, ox[r], s[u].w)));
+        float disc = __builtin_fmaf(hb, hb, __builtin_fmaf(qh, 2.0f, noo[r]));
+        m = max(m, __float_as_int(disc));
+      }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= 0) != 0, 0)) cnt += (m >= 0);
+  };
+  auto block_s = [&](const cf4 (&s)[4]) {
+    int m = (int)0x80000000;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float hb = __builtin_fmaf(s[u].z, nz[r], __builtin_fmaf(s[u].y, ny[r], __builtin_fmaf(s[u].x, nx[r], od[r])));
+        float t = __builtin_fmaf(s[u].z, oz[r], __builtin_fmaf(s[u].y, oy[r], __builtin_fmaf(s[u].x, ox[r], hnoo[r])));
+        float disc = __builtin_fmaf(hb, hb, __builtin_fmaf(t, 2.0f, s[u].w));
+        m = max(m, __float_as_int(disc));
+      }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= 0) != 0, 0)) cnt += (m >= 0);
+  };
+  constexpr int STEP = 4 * (LDS_BLOCKS + 1);
+  for (int rep = 0; rep < reps; ++rep) {
+    float4 A[4];
+    cf4 S[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      A[u] = lds[u];
+      S[u] = sp[4 * LDS_BLOCKS + u];
+    }
+    for (int i = 0; i + STEP <= n; i += STEP) {
+      // the scalar block of the NEXT round is requested now and carried around the loop, so
+      // its latency hides behind this round's arithmetic (the buffer is padded for it)
+      cf4 Sn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Sn[u] = sp[i + STEP + 4 * LDS_BLOCKS + u];
+#pragma unroll
+      for (int b = 0; b < LDS_BLOCKS; ++b) {
+        float4 N[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) N[u] = lds[i + 4 * (b + 1) + (b + 1 == LDS_BLOCKS ? 4 : 0) + u];
+        __builtin_amdgcn_sched_barrier(0);
+        block_v(A);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) A[u] = N[u];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      block_s(S);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) S[u] = Sn[u];
+    }
+    ox[0] += 1e-6f;
+  }
+  out[tid] = (float)cnt;
+}
+
 static float time_ms(hipEvent_t e0, hipEvent_t e1) { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
 
 int main(int argc, char** argv) {
@@ -561,11 +708,11 @@ int main(int argc, char** argv) {
 
 
   if (argc > 2 && !strcmp(argv[2], "ahead")) {
-    const int n = 488, reps = 400;
+    const int n = (argc > 3 && !strcmp(argv[3], "mixed")) ? 480 : 488, reps = 400;
     std::vector<float4> hs(n);
     for (int i = 0; i < n; ++i) hs[i] = make_float4((i % 22) - 11 + 0.3f, 0.2f, (i / 22) - 11 + 0.4f, -1e6f);
-    float4* ds; CK(hipMalloc(&ds, sizeof(float4) * (n + 8)));   // padded for the read-ahead
-    CK(hipMemset(ds, 0, sizeof(float4) * (n + 8)));
+    float4* ds; CK(hipMalloc(&ds, sizeof(float4) * (n + 32)));   // padded for the read-ahead
+    CK(hipMemset(ds, 0, sizeof(float4) * (n + 32)));
     CK(hipMemcpy(ds, hs.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     auto run = [&](const char* name, auto kern, int R, int wps, int threads) {
       int blocks = cus * wps * 256 / threads;
@@ -582,6 +729,25 @@ int main(int argc, char** argv) {
       printf("%-14s paths/lane %d waves/SIMD %d : %8.3f ms  %7.2f Gtests/s  = %5.1f%% of 157.3 TF at 17 flop/test\n",
              name, R, wps, best, tests / best * 1e-6, tests * 17 / best * 1e-9 / 157.3 * 100);
     };
+    if (argc > 3 && !strcmp(argv[3], "mixed")) {
+      // n is rounded down to whole rounds by each kernel; 480 = 40 rounds of 12, 30 of 16, 60 of 8
+      for (int wps : {4, 8}) {
+        run("ahead(lds)", (k_cons_ahead<2, false>), 2, wps, 256);
+        run("mixed 1+1", (k_cons_mixed<2, 1>), 2, wps, 256);
+        run("mixed 2+1", (k_cons_mixed<2, 2>), 2, wps, 256);
+        run("mixed 3+1", (k_cons_mixed<2, 3>), 2, wps, 256);
+      }
+      return 0;
+    }
+    if (argc > 3 && !strcmp(argv[3], "spairs")) {
+      for (int wps : {2, 4, 8}) {
+        run("ahead(plain)", (k_cons_ahead<2, false>), 2, wps, 256);
+        run("sphere_pairs", (k_cons_sphere_pairs<2>), 2, wps, 256);
+        run("ahead(plain)", (k_cons_ahead<4, false>), 4, wps, 256);
+        run("sphere_pairs", (k_cons_sphere_pairs<4>), 4, wps, 256);
+      }
+      return 0;
+    }
     if (argc > 3 && !strcmp(argv[3], "smem")) {
       for (int wps : {4, 5, 6, 8}) {
         run("ahead(lds)", (k_cons_ahead<2, false>), 2, wps, 256);
