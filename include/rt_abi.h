@@ -11,7 +11,9 @@
  *    available from rt_last_error() (thread-local).  Nothing aborts and nothing throws.
  *  - the caller owns every buffer it passes; the library keeps no pointer after a call returns
  *    (rt_scene objects own their own device copies).
- *  - calls are blocking unless the name ends in _async; one host thread at a time per process.
+ *  - calls are blocking unless the name ends in _async.  The library keeps one set
+ *    of contexts per process behind one lock: calls from several host threads are serialised,
+ *    never concurrent.  Every call leaves the calling thread's current HIP device as it found it.
  *  - results are a pure function of (seed, scene, camera, W, H, spp, max_depth, flags): they do
  *    not depend on tiling, on launch geometry or on how many GPUs share the frame.
  */
@@ -86,8 +88,9 @@ typedef struct rt_tile {
                                      bit-identical to the scan's */
 
 /* Mirror of `struct Dispatch` (reference src/cpu/mod.rs:19-30) plus the render seed.
- * `tiles` may be NULL for rt_render() (the GPU path does not need the caller's tiling);
- * rt_render_tiles() requires it. */
+ * rt_render() renders exactly the listed tiles and leaves every other pixel (0,0,0), like the
+ * reference's compose_final_framebuffer (src/cpu/mod.rs:57-80); `tiles` == NULL (or a list that
+ * covers the image) means the whole frame.  rt_render_tiles() requires the list. */
 typedef struct rt_request {
   uint32_t image_width;
   uint32_t image_height;

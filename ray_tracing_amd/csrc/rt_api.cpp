@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,16 +19,23 @@
 #include "rt_internal.h"
 
 struct rt_scene {
-  rt::SceneDev dev;
+  // `dev` and the hierarchy's buffers change when the hierarchy is built on first use, which
+  // happens behind a `const rt_scene*` (the scene the caller sees does not change)
+  mutable rt::SceneDev dev;
   void* trig = nullptr;
   void* geom = nullptr;
   void* aux = nullptr;
   void* mat = nullptr;
-  void* bvh = nullptr;          // RT_FLAG_ACCEL: nodes, permuted geometry, original indices
-  void* leaf_geom = nullptr;
-  void* leaf_index = nullptr;
-  uint32_t bvh_depth = 0;
+  mutable void* bvh = nullptr;  // RT_FLAG_ACCEL: nodes, permuted geometry, original indices
+  mutable void* leaf_geom = nullptr;
+  mutable void* leaf_index = nullptr;
+  mutable uint32_t bvh_depth = 0;
+  mutable bool bvh_built = false;
   int device = -1;
+  // host copies: what the hierarchy is built from, and what rt_render compares a request's
+  // world with to decide whether the device copy it kept from the last call still serves
+  std::vector<rt_sphere> host_spheres;
+  std::vector<rt_material> host_materials;
 };
 
 namespace {
@@ -54,6 +62,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kEventRing = 64;
 constexpr int kLaunchSlots = 4;
+constexpr int kCopyChunks = 8;   // pieces a frame goes back to the host in (rt_render)
 
 // What one in-flight render owns on the device.  Launches on the same stream run one after the
 // other and share a slot; launches on different streams may overlap on the GPU, so each stream
@@ -67,7 +76,20 @@ struct LaunchSlot {
   size_t partial_cap = 0;                 // in floats
   uint64_t last_use = 0;
   rt_stats last = {};
-  int event = -1;                         // index in the event ring of the slot's last launch
+  uint64_t launch_no = 0;                 // 1-based number of the slot's last launch; 0 = none
+};
+
+// What the host-pointer entry points keep between calls on one device: the device copy of the
+// last World they were given, the frame in device memory and a pinned staging buffer.  A host
+// that renders frame after frame of one scene (the reference's main() renders the same World
+// twice, src/main.rs:905-937) then pays for upload and allocation once.
+struct FrameCache {
+  rt_scene* scene = nullptr;
+  float* frame = nullptr;                 // device
+  size_t frame_cap = 0;                   // floats
+  float* pinned = nullptr;                // host, page-locked
+  size_t pinned_cap = 0;                  // floats
+  hipEvent_t copied[kCopyChunks] = {};
 };
 
 struct State {
@@ -76,12 +98,13 @@ struct State {
   int cus = 0;
   hipStream_t stream = nullptr;
   LaunchSlot slots[kLaunchSlots];
-  int last_slot = -1;
+  LaunchSlot* last_slot = nullptr;
   rt::TileDev* tiles = nullptr;           // device, grow-only
   size_t tiles_cap = 0;
   std::vector<rt::TileDev> tiles_host;    // what ctx().tiles currently holds
   hipEvent_t ev_begin[kEventRing], ev_end[kEventRing];
   uint64_t launches = 0;
+  FrameCache cache;
 };
 // One State per GPU the process drives.  Context 0 is the one rt_init() makes; rt_render_multi
 // adds one per listed device and puts it in charge (ctx()) around the calls it makes for that
@@ -90,6 +113,31 @@ State g_primary;
 std::vector<State*> g_extra;     // contexts of rt_render_multi, by position in its device list
 State* g_cur = &g_primary;
 inline State& ctx() { return *g_cur; }
+
+// The contexts are process-wide and unsynchronised; every entry point takes this lock, so calls
+// from several host threads are serialised rather than racing (entry points call each other,
+// hence recursive).
+std::recursive_mutex g_api_mutex;
+
+// An entry point runs with the library's device current and gives the calling thread its own
+// current device back when it leaves (the caller's, and its framework's, notion of the current
+// device is not ours to change).
+class ApiScope {
+ public:
+  ApiScope() : lock_(g_api_mutex) {
+    if (hipGetDevice(&saved_) != hipSuccess) {
+      (void)hipGetLastError();
+      saved_ = -1;
+    }
+  }
+  ~ApiScope() {
+    if (saved_ >= 0) (void)hipSetDevice(saved_);
+  }
+
+ private:
+  std::lock_guard<std::recursive_mutex> lock_;
+  int saved_ = -1;
+};
 
 int acquire_slot(hipStream_t stream, LaunchSlot** out) {
   int pick = -1;
@@ -108,7 +156,6 @@ int acquire_slot(hipStream_t stream, LaunchSlot** out) {
     ctx().slots[pick].bound = true;
   }
   ctx().slots[pick].last_use = ctx().launches + 1;
-  ctx().last_slot = pick;
   *out = &ctx().slots[pick];
   return RT_OK;
 }
@@ -140,8 +187,25 @@ float trigger_constant(const rt_sphere& s) {
 int check_ready() {
   if (!ctx().ready) return fail(RT_ERR_NOT_INITIALIZED, "rt_init() has not been called");
   // every call below allocates, copies or launches on the library's device, whatever device
-  // the caller made current in between
+  // the caller made current in between (ApiScope puts the caller's back afterwards)
   RT_HIP(hipSetDevice(ctx().device));
+  return RT_OK;
+}
+
+// A device-resident output must live on the library's device (or be host memory the device can
+// write, which HIP reports as such); a pointer HIP does not know cannot be written by a kernel.
+int check_device_pointer(const void* p, const char* what) {
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof attr);
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(RT_ERR_INVALID_ARGUMENT, "%s is not memory the device can reach", what);
+  }
+  if (attr.type == hipMemoryTypeDevice && attr.device != ctx().device)
+    return fail(RT_ERR_INVALID_ARGUMENT, "%s lives on device %d, the library on device %d", what,
+                attr.device, ctx().device);
+  if (attr.type == hipMemoryTypeUnregistered)
+    return fail(RT_ERR_INVALID_ARGUMENT, "%s is pageable host memory, not device memory", what);
   return RT_OK;
 }
 
@@ -168,12 +232,13 @@ int check_frame(const rt_frame* f) {
 //  * small images: fewer pixels than lanes.
 // The cut is a function of the FULL image and spp only, so a frame gives the same sums
 // whatever part of it a call renders and however many GPUs share it.
-std::vector<uint32_t> plan_slices(const rt_frame& f, uint32_t* body_slices) {
+// Writes begin[0..n] and returns n, the number of slices (at most rt::kMaxSlices).
+uint32_t plan_slices(const rt_frame& f, uint32_t* begin, uint32_t* body_slices) {
   const uint32_t spp = f.samples_per_pixel;
-  std::vector<uint32_t> sizes;
-  uint32_t tail = 0;
+  uint32_t sizes[rt::kMaxSlices];
+  uint32_t n = 0, tail = 0;
   if (f.flags & RT_FLAG_SEQUENTIAL_SUM) {
-    sizes.push_back(spp);
+    sizes[n++] = spp;
   } else {
     // Full-size items run `big` samples: at most kSamplesPerItem, and no more than ~2 % of what
     // one lane-slot gets when the frame is split over 8 GPUs (a lane runs an item to its end,
@@ -189,12 +254,12 @@ std::vector<uint32_t> plan_slices(const rt_frame& f, uint32_t* body_slices) {
     const uint32_t room = rt::kMaxSlices - (use_taper ? 8 : 0);
     if ((body + big - 1) / big > room) big = (body + room - 1) / room;
     for (uint32_t left = body; left > 0;) {
-      const uint32_t n = left < big ? left : big;
-      sizes.push_back(n);
-      left -= n;
+      const uint32_t k = left < big ? left : big;
+      sizes[n++] = k;
+      left -= k;
     }
     if (use_taper) {
-      for (uint32_t t : taper) sizes.push_back(t);
+      for (uint32_t t : taper) sizes[n++] = t;
       tail = 8;
     }
     // small image: more, equal slices so that every lane has an item
@@ -202,28 +267,72 @@ std::vector<uint32_t> plan_slices(const rt_frame& f, uint32_t* body_slices) {
     uint64_t want = pixels >= rt::kTargetItems ? 1 : (rt::kTargetItems + pixels - 1) / pixels;
     if (want > spp) want = spp;
     if (want > rt::kMaxSlices) want = rt::kMaxSlices;
-    if (want > sizes.size()) {
-      sizes.clear();
+    if (want > n) {
+      n = 0;
       tail = 0;
       for (uint64_t k = 0; k < want; ++k)
-        sizes.push_back((uint32_t)(((k + 1) * spp) / want - (k * spp) / want));
+        sizes[n++] = (uint32_t)(((k + 1) * spp) / want - (k * spp) / want);
     }
   }
-  std::vector<uint32_t> begin(1, 0);
-  for (uint32_t n : sizes) begin.push_back(begin.back() + n);
-  *body_slices = (uint32_t)sizes.size() - tail;
-  return begin;
+  begin[0] = 0;
+  for (uint32_t k = 0; k < n; ++k) begin[k + 1] = begin[k] + sizes[k];
+  *body_slices = n - tail;
+  return n;
+}
+
+// The optional hierarchy (RT_FLAG_ACCEL) is built the first time a scene is rendered with it:
+// a scene that only ever takes the linear scan pays nothing for it.
+int ensure_bvh(const rt_scene* s) {
+  if (s->bvh_built) return RT_OK;
+  rt::BvhHost bvh;
+  rt::build_bvh(s->host_spheres.data(), (uint32_t)s->host_spheres.size(), &bvh);
+  const size_t nn = bvh.nodes.empty() ? 1 : bvh.nodes.size();
+  const size_t nl = bvh.leaf_geom.empty() ? 1 : bvh.leaf_geom.size();
+  RT_HIP(hipMalloc(&s->bvh, nn * sizeof(rt::BvhNode)));
+  RT_HIP(hipMalloc(&s->leaf_geom, nl * sizeof(float4)));
+  RT_HIP(hipMalloc(&s->leaf_index, nl * sizeof(uint32_t)));
+  if (!bvh.nodes.empty())
+    RT_HIP(hipMemcpy(s->bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rt::BvhNode),
+                     hipMemcpyHostToDevice));
+  if (!bvh.leaf_geom.empty()) {
+    RT_HIP(hipMemcpy(s->leaf_geom, bvh.leaf_geom.data(), bvh.leaf_geom.size() * sizeof(float4),
+                     hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(s->leaf_index, bvh.leaf_index.data(),
+                     bvh.leaf_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  s->bvh_depth = bvh.depth;
+  s->dev.bvh_info = bvh.info;
+  s->dev.bvh = (const rt::BvhNode*)s->bvh;
+  s->dev.leaf_geom = (const float4*)s->leaf_geom;
+  s->dev.leaf_index = (const uint32_t*)s->leaf_index;
+  s->bvh_built = true;
+  return RT_OK;
+}
+
+// Launch-geometry queries do not change for the life of the process; asking once per kernel
+// variant keeps the call path of a frame down to its launches.
+int blocks_per_cu(bool strict, bool multi, bool accel, size_t lds, int* out) {
+  struct Entry { bool valid; size_t lds; int per_cu; };
+  static Entry cache[8] = {};
+  Entry& e = cache[(strict ? 1 : 0) | (multi ? 2 : 0) | (accel ? 4 : 0)];
+  if (!e.valid || e.lds != lds) {
+    int per_cu = 0;
+    RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, accel, lds, &per_cu));
+    e.valid = true;
+    e.lds = lds;
+    e.per_cu = per_cu;
+  }
+  *out = e.per_cu;
+  return RT_OK;
 }
 
 // `sample_begin` / `accumulate`: the call adds samples [sample_begin, sample_begin + spp) of
 // every pixel to what d_out already holds (progressive rendering; resolve must be 0).
-int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
-                        const std::vector<rt::TileDev>& tiles, uint64_t out_pixels, int resolve,
-                        float* d_out, hipStream_t stream, uint32_t sample_begin = 0,
-                        bool accumulate = false) {
+int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::TileDev* tiles,
+                        size_t n_tiles, uint64_t out_pixels, int resolve, float* d_out,
+                        hipStream_t stream, uint32_t sample_begin = 0, bool accumulate = false) {
   rt::TraceParams p;
   memset(&p, 0, sizeof p);
-  p.scene = scene->dev;
   p.cam = frame->camera;
   // origin = view_inv * (0,0,0,1) in glam's order ((c0*x + c1*y) + c2*z) + c3*w
   for (int i = 0; i < 3; ++i) {
@@ -240,12 +349,12 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   p.spp = frame->samples_per_pixel;
   p.seed_a = rt_rng_seed_a(frame->seed);
   p.seed_b = rt_rng_seed_b(frame->seed);
-  const std::vector<uint32_t> slice_begin = plan_slices(*frame, &p.body_slices);
-  p.slices = (uint32_t)slice_begin.size() - 1;
-  for (size_t k = 0; k < slice_begin.size(); ++k) p.slice_begin[k] = sample_begin + slice_begin[k];
-  p.n_tiles = (uint32_t)tiles.size();
+  uint32_t slice_begin[rt::kMaxSlices + 1];
+  p.slices = plan_slices(*frame, slice_begin, &p.body_slices);
+  for (uint32_t k = 0; k <= p.slices; ++k) p.slice_begin[k] = sample_begin + slice_begin[k];
+  p.n_tiles = (uint32_t)n_tiles;
   uint64_t total_pixels = 0;
-  for (const rt::TileDev& t : tiles) total_pixels += (uint64_t)t.w * t.h;
+  for (size_t i = 0; i < n_tiles; ++i) total_pixels += (uint64_t)tiles[i].w * tiles[i].h;
   if (total_pixels == 0) return RT_OK;
   if (total_pixels * p.slices >= 0xFFFFFF00ull || out_pixels * p.slices >= 0xFFFFFF00ull)
     return fail(RT_ERR_LIMIT, "more than 2^32 work items in one call");
@@ -256,60 +365,83 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   if (scene->device != ctx().device)
     return fail(RT_ERR_INVALID_ARGUMENT, "scene lives on device %d, the library on device %d",
                 scene->device, ctx().device);
+
+  const bool strict = (frame->flags & RT_FLAG_STRICT_FP) != 0;
+  const bool accel = (frame->flags & RT_FLAG_ACCEL) != 0;
+  if (accel) {
+    if (int rc = ensure_bvh(scene)) return rc;
+    if (scene->bvh_depth > rt::bvh_stack_depth())
+      return fail(RT_ERR_LIMIT, "hierarchy of %u levels exceeds the traversal stack (%u)",
+                  scene->bvh_depth, rt::bvh_stack_depth());
+  }
+  p.scene = scene->dev;
+
+  const size_t partial_need = p.slices > 1 ? (size_t)out_pixels * 3 * p.slices : 0;
   LaunchSlot* slot = nullptr;
   if (int rc = acquire_slot(stream, &slot)) return rc;
   p.counters = slot->counters;
 
-  const bool strict = (frame->flags & RT_FLAG_STRICT_FP) != 0;
-  const bool accel = (frame->flags & RT_FLAG_ACCEL) != 0;
-  if (accel && scene->bvh_depth > rt::bvh_stack_depth())
-    return fail(RT_ERR_LIMIT, "hierarchy of %u levels exceeds the traversal stack (%u)",
-                scene->bvh_depth, rt::bvh_stack_depth());
-
-  if (frame->max_depth == 0) {
-    // shoot_ray(ray, 0) is black (src/main.rs:192-194): every sum is 0 and nothing is traced
-    if (!accumulate) RT_HIP(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(float), stream));
-    slot->last = {};
-    slot->last.samples = total_pixels * frame->samples_per_pixel;
-    slot->event = -1;
-    return RT_OK;
-  }
-
-  if (tiles.size() == 1) {
+  if (n_tiles == 1) {
     p.tile0 = tiles[0];
     p.tiles = nullptr;
   } else {
     // The table lives in one grow-only device buffer.  A caller that renders the same tile
     // list frame after frame (a rank's row blocks) pays for the upload once.
-    const bool same = ctx().tiles_host.size() == tiles.size() &&
-                      memcmp(ctx().tiles_host.data(), tiles.data(), tiles.size() * sizeof(rt::TileDev)) == 0;
+    const bool same = ctx().tiles_host.size() == n_tiles &&
+                      memcmp(ctx().tiles_host.data(), tiles, n_tiles * sizeof(rt::TileDev)) == 0;
     if (!same) {
       RT_HIP(hipDeviceSynchronize());   // an earlier launch, on any stream, may still read it
-      if (tiles.size() > ctx().tiles_cap) {
+      if (n_tiles > ctx().tiles_cap) {
         if (ctx().tiles) RT_HIP(hipFree(ctx().tiles));
         ctx().tiles = nullptr;
         ctx().tiles_cap = 0;
         ctx().tiles_host.clear();
-        RT_HIP(hipMalloc((void**)&ctx().tiles, tiles.size() * sizeof(rt::TileDev)));
-        ctx().tiles_cap = tiles.size();
+        RT_HIP(hipMalloc((void**)&ctx().tiles, n_tiles * sizeof(rt::TileDev)));
+        ctx().tiles_cap = n_tiles;
       }
-      RT_HIP(hipMemcpy(ctx().tiles, tiles.data(), tiles.size() * sizeof(rt::TileDev),
-                       hipMemcpyHostToDevice));
-      ctx().tiles_host = tiles;
+      RT_HIP(hipMemcpy(ctx().tiles, tiles, n_tiles * sizeof(rt::TileDev), hipMemcpyHostToDevice));
+      ctx().tiles_host.assign(tiles, tiles + n_tiles);
     }
     p.tiles = ctx().tiles;
   }
 
+  rt::ReduceParams rp;
+  memset(&rp, 0, sizeof rp);
+  rp.out = d_out;
+  rp.out_pixels = out_pixels;
+  rp.n_tiles = p.n_tiles;
+  rp.total_pixels = p.total_pixels;
+  rp.tile0 = p.tile0;
+  rp.tiles = p.tiles;
+  rp.resolve = resolve;
+  rp.accumulate = accumulate ? 1 : 0;
+  rp.inv_spp = p.inv_spp;
+
+  if (frame->max_depth == 0) {
+    // shoot_ray(ray, 0) is black (src/main.rs:192-194): every sum is 0 and nothing is traced.
+    // Only the pixels the tiles cover are written, like in every other case (the gaps of a
+    // strided output may belong to another call); adding zero to a running sum changes nothing.
+    if (!accumulate) {
+      rp.partial = nullptr;
+      rp.slices = 0;
+      RT_HIP(rt::launch_reduce(rp, stream));
+    }
+    slot->last = {};
+    slot->last.samples = total_pixels * frame->samples_per_pixel;
+    slot->launch_no = 0;
+    ctx().last_slot = slot;
+    return RT_OK;
+  }
+
   float* trace_out = d_out;
   if (p.slices > 1) {
-    const size_t need = (size_t)out_pixels * 3 * p.slices;
-    if (need > slot->partial_cap) {
+    if (partial_need > slot->partial_cap) {
       RT_HIP(hipStreamSynchronize(stream));   // the slot's earlier launches read the old buffer
       if (slot->partial) RT_HIP(hipFree(slot->partial));
       slot->partial = nullptr;
       slot->partial_cap = 0;
-      RT_HIP(hipMalloc((void**)&slot->partial, need * sizeof(float)));
-      slot->partial_cap = need;
+      RT_HIP(hipMalloc((void**)&slot->partial, partial_need * sizeof(float)));
+      slot->partial_cap = partial_need;
     }
     trace_out = slot->partial;
     p.resolve = 0;
@@ -326,7 +458,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   p.bvh_in_lds = bvh_in_lds ? 1 : 0;
   const bool multi = scene->dev.n_spheres > rt::kChunkSpheres;
   int per_cu = 0;
-  RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, accel, lds, &per_cu));
+  if (int rc = blocks_per_cu(strict, multi, accel, lds, &per_cu)) return rc;
   if (per_cu < 1) return fail(RT_ERR_DEVICE, "trace kernel does not fit on a CU (LDS %zu B)", lds);
   int blocks = per_cu * ctx().cus;
   const uint32_t paths_per_lane = accel ? 1 : rt::kRaysPerLane;
@@ -336,30 +468,22 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
   if (blocks < 1) blocks = 1;
 
+  // the counters must start at zero; the planes need no clearing (every covered pixel of every
+  // plane is written by the trace kernel before the reduce kernel reads it)
   RT_HIP(hipMemsetAsync(slot->counters, 0, sizeof(rt::Counters), stream));
   const int ev = (int)(ctx().launches % kEventRing);
   RT_HIP(hipEventRecord(ctx().ev_begin[ev], stream));
   RT_HIP(rt::launch_trace(p, strict, accel, blocks, stream));
   RT_HIP(hipEventRecord(ctx().ev_end[ev], stream));
   ctx().launches++;
-  slot->event = ev;
 
   if (p.slices > 1) {
-    rt::ReduceParams rp;
     rp.partial = slot->partial;
-    rp.out = d_out;
-    rp.out_pixels = out_pixels;
     rp.slices = p.slices;
-    rp.n_tiles = p.n_tiles;
-    rp.total_pixels = p.total_pixels;
-    rp.tile0 = p.tile0;
-    rp.tiles = p.tiles;
-    rp.resolve = resolve;
-    rp.accumulate = accumulate ? 1 : 0;
-    rp.inv_spp = p.inv_spp;
     RT_HIP(rt::launch_reduce(rp, stream));
   }
 
+  slot->launch_no = ctx().launches;
   slot->last = {};
   slot->last.rays_per_lane = paths_per_lane;
   slot->last.slices = p.slices;
@@ -367,6 +491,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame,
   slot->last.threads_per_workgroup = threads;
   // multiplied by rays in rt_get_stats; a traversal does not count its tests
   slot->last.sphere_tests = accel ? 0 : scene->dev.n_spheres;
+  ctx().last_slot = slot;
   return RT_OK;
 }
 
@@ -440,6 +565,8 @@ int init_context(int device) {
     RT_HIP(hipEventCreate(&ctx().ev_begin[i]));
     RT_HIP(hipEventCreate(&ctx().ev_end[i]));
   }
+  for (int i = 0; i < kCopyChunks; ++i)
+    RT_HIP(hipEventCreateWithFlags(&ctx().cache.copied[i], hipEventDisableTiming));
   ctx().device = device;
   ctx().launches = 0;
   ctx().ready = true;
@@ -458,6 +585,12 @@ void destroy_context() {
     if (sl.counters) (void)hipFree(sl.counters);
     if (sl.partial) (void)hipFree(sl.partial);
   }
+  FrameCache& fc = ctx().cache;
+  for (int i = 0; i < kCopyChunks; ++i)
+    if (fc.copied[i]) (void)hipEventDestroy(fc.copied[i]);
+  if (fc.scene) (void)rt_scene_destroy(fc.scene);
+  if (fc.frame) (void)hipFree(fc.frame);
+  if (fc.pinned) (void)hipHostFree(fc.pinned);
   if (ctx().tiles) (void)hipFree(ctx().tiles);
   if (ctx().stream) (void)hipStreamDestroy(ctx().stream);
   ctx() = State();
@@ -465,6 +598,7 @@ void destroy_context() {
 }  // namespace
 
 int rt_init(int device) {
+  ApiScope scope;
   g_cur = &g_primary;
   if (ctx().ready) {
     if (ctx().device == device) return RT_OK;
@@ -474,6 +608,7 @@ int rt_init(int device) {
 }
 
 int rt_shutdown(void) {
+  ApiScope scope;
   for (State* ctx : g_extra) {
     g_cur = ctx;
     destroy_context();
@@ -487,6 +622,7 @@ int rt_shutdown(void) {
 
 int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_material* materials,
                     uint32_t n_materials, rt_scene** out_scene) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
   if (!out_scene) return fail(RT_ERR_INVALID_ARGUMENT, "out_scene is NULL");
   *out_scene = nullptr;
@@ -504,7 +640,6 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
     if (!(mag < 1e37))
       return fail(RT_ERR_LIMIT, "sphere %u: centre or radius not finite or beyond 1e18", i);
   }
-  RT_HIP(hipSetDevice(ctx().device));
 
   std::vector<float4> trig(n_spheres ? n_spheres : 1);
   std::vector<float4> geom(n_spheres ? n_spheres : 1);
@@ -527,45 +662,26 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
   }
   rt_scene* s = new rt_scene();
   s->device = ctx().device;
+  if (n_spheres) s->host_spheres.assign(spheres, spheres + n_spheres);
+  if (n_materials) s->host_materials.assign(materials, materials + n_materials);
   ScopedScene guard;
   guard.s = s;
   RT_HIP(hipMalloc(&s->trig, trig.size() * sizeof(float4)));
-  RT_HIP(hipMemcpy(s->trig, trig.data(), trig.size() * sizeof(float4), hipMemcpyHostToDevice));
-  s->dev.trig = (const float4*)s->trig;
   RT_HIP(hipMalloc(&s->geom, geom.size() * sizeof(float4)));
   RT_HIP(hipMalloc(&s->aux, aux.size() * sizeof(float2)));
   RT_HIP(hipMalloc(&s->mat, mat.size() * sizeof(float4)));
+  RT_HIP(hipMemcpy(s->trig, trig.data(), trig.size() * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(s->geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(s->aux, aux.data(), aux.size() * sizeof(float2), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(s->mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
+  memset(&s->dev, 0, sizeof s->dev);
+  s->dev.trig = (const float4*)s->trig;
   s->dev.geom = (const float4*)s->geom;
   s->dev.aux = (const float2*)s->aux;
   s->dev.mat = (const float4*)s->mat;
   s->dev.n_spheres = n_spheres;
   s->dev.n_materials = n_materials;
-
-  // the optional hierarchy (RT_FLAG_ACCEL)
-  rt::BvhHost bvh;
-  rt::build_bvh(spheres, n_spheres, &bvh);
-  s->bvh_depth = bvh.depth;
-  s->dev.bvh_info = bvh.info;
-  const size_t nn = bvh.nodes.empty() ? 1 : bvh.nodes.size();
-  const size_t nl = bvh.leaf_geom.empty() ? 1 : bvh.leaf_geom.size();
-  RT_HIP(hipMalloc(&s->bvh, nn * sizeof(rt::BvhNode)));
-  RT_HIP(hipMalloc(&s->leaf_geom, nl * sizeof(float4)));
-  RT_HIP(hipMalloc(&s->leaf_index, nl * sizeof(uint32_t)));
-  if (!bvh.nodes.empty())
-    RT_HIP(hipMemcpy(s->bvh, bvh.nodes.data(), bvh.nodes.size() * sizeof(rt::BvhNode),
-                     hipMemcpyHostToDevice));
-  if (!bvh.leaf_geom.empty()) {
-    RT_HIP(hipMemcpy(s->leaf_geom, bvh.leaf_geom.data(), bvh.leaf_geom.size() * sizeof(float4),
-                     hipMemcpyHostToDevice));
-    RT_HIP(hipMemcpy(s->leaf_index, bvh.leaf_index.data(),
-                     bvh.leaf_index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  }
-  s->dev.bvh = (const rt::BvhNode*)s->bvh;
-  s->dev.leaf_geom = (const float4*)s->leaf_geom;
-  s->dev.leaf_index = (const uint32_t*)s->leaf_index;
+  s->dev.bvh_info = rt::BvhInfo();   // the hierarchy is built on first use (ensure_bvh)
   guard.s = nullptr;
   *out_scene = s;
   return RT_OK;
@@ -573,6 +689,8 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
 
 int rt_scene_destroy(rt_scene* scene) {
   if (!scene) return RT_OK;
+  ApiScope scope;
+  if (scene->device >= 0) (void)hipSetDevice(scene->device);
   if (scene->trig) (void)hipFree(scene->trig);
   if (scene->geom) (void)hipFree(scene->geom);
   if (scene->aux) (void)hipFree(scene->aux);
@@ -611,28 +729,50 @@ int tile_table(const rt_frame* frame, const rt_tile* tiles, const uint64_t* out_
   *out_pixels_total = out_pixels;
   return RT_OK;
 }
+
+rt::TileDev rows_tile(const rt_frame* frame, uint32_t row_begin, uint32_t row_end) {
+  rt::TileDev t;
+  memset(&t, 0, sizeof t);
+  t.x = 0; t.y = row_begin; t.w = frame->image_width; t.h = row_end - row_begin;
+  t.first_pixel = 0;
+  t.out_stride = frame->image_width;
+  t.out_offset = 0;
+  return t;
+}
+
+int check_rows(const rt_scene* scene, const rt_frame* frame, uint32_t row_begin, uint32_t row_end) {
+  if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
+  if (int rc = check_frame(frame)) return rc;
+  if (row_begin > row_end || row_end > frame->image_height)
+    return fail(RT_ERR_INVALID_ARGUMENT, "rows [%u,%u) of %u", row_begin, row_end,
+                frame->image_height);
+  return RT_OK;
+}
 }  // namespace
 
 int rt_render_device_async(const rt_scene* scene, const rt_frame* frame, const rt_tile* tiles,
                            const uint64_t* out_offset, const uint32_t* out_stride,
                            uint32_t n_tiles, int resolve, float* d_out, void* stream) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
   if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
   if (int rc = check_frame(frame)) return rc;
   if (n_tiles == 0) return RT_OK;
   if (!tiles || !out_offset || !out_stride || !d_out)
     return fail(RT_ERR_INVALID_ARGUMENT, "NULL tile table or output");
+  if (int rc = check_device_pointer(d_out, "d_out")) return rc;
   std::vector<rt::TileDev> td;
   uint64_t out_pixels = 0;
   if (int rc = tile_table(frame, tiles, out_offset, out_stride, n_tiles, &td, &out_pixels)) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
-  return render_tiles_device(scene, frame, td, out_pixels, resolve, d_out, s);
+  return render_tiles_device(scene, frame, td.data(), td.size(), out_pixels, resolve, d_out, s);
 }
 
 int rt_accumulate_device_async(const rt_scene* scene, const rt_frame* frame, uint32_t sample_begin,
                                const rt_tile* tiles, const uint64_t* out_offset,
                                const uint32_t* out_stride, uint32_t n_tiles, float* d_sums,
                                void* stream) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
   if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
   if (int rc = check_frame(frame)) return rc;
@@ -641,15 +781,18 @@ int rt_accumulate_device_async(const rt_scene* scene, const rt_frame* frame, uin
   if (n_tiles == 0) return RT_OK;
   if (!tiles || !out_offset || !out_stride || !d_sums)
     return fail(RT_ERR_INVALID_ARGUMENT, "NULL tile table or output");
+  if (int rc = check_device_pointer(d_sums, "d_sums")) return rc;
   std::vector<rt::TileDev> td;
   uint64_t out_pixels = 0;
   if (int rc = tile_table(frame, tiles, out_offset, out_stride, n_tiles, &td, &out_pixels)) return rc;
   hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
-  return render_tiles_device(scene, frame, td, out_pixels, 0, d_sums, s, sample_begin, true);
+  return render_tiles_device(scene, frame, td.data(), td.size(), out_pixels, 0, d_sums, s,
+                             sample_begin, true);
 }
 
 int rt_resolve_device_async(const float* d_sums, uint64_t n_pixels, uint32_t samples_per_pixel,
                             float* d_rgb, void* stream) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
   if (n_pixels == 0) return RT_OK;
   if (!d_sums || !d_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "NULL buffer");
@@ -665,39 +808,33 @@ int rt_resolve_device_async(const float* d_sums, uint64_t n_pixels, uint32_t sam
 
 int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame, uint32_t row_begin,
                                 uint32_t row_end, int resolve, float* d_out, void* stream) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
-  if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
-  if (int rc = check_frame(frame)) return rc;
-  if (row_begin > row_end || row_end > frame->image_height)
-    return fail(RT_ERR_INVALID_ARGUMENT, "rows [%u,%u) of %u", row_begin, row_end,
-                frame->image_height);
+  if (int rc = check_rows(scene, frame, row_begin, row_end)) return rc;
   if (row_begin == row_end) return RT_OK;
   if (!d_out) return fail(RT_ERR_INVALID_ARGUMENT, "d_out is NULL");
-  rt::TileDev t;
-  memset(&t, 0, sizeof t);
-  t.x = 0; t.y = row_begin; t.w = frame->image_width; t.h = row_end - row_begin;
-  t.first_pixel = 0;
-  t.out_stride = frame->image_width;
-  t.out_offset = 0;
-  std::vector<rt::TileDev> td(1, t);
+  if (int rc = check_device_pointer(d_out, "d_out")) return rc;
+  const rt::TileDev t = rows_tile(frame, row_begin, row_end);
   hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
-  return render_tiles_device(scene, frame, td, (uint64_t)t.w * t.h, resolve, d_out, s);
+  return render_tiles_device(scene, frame, &t, 1, (uint64_t)t.w * t.h, resolve, d_out, s);
 }
 
 int rt_synchronize(void* stream) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
   RT_HIP(hipStreamSynchronize(stream ? (hipStream_t)stream : ctx().stream));
   return RT_OK;
 }
 
 int rt_get_stats(rt_stats* out) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
   if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is NULL");
-  if (ctx().last_slot < 0) {
+  if (!ctx().last_slot) {
     *out = rt_stats{};
     return RT_OK;
   }
-  const LaunchSlot& sl = ctx().slots[ctx().last_slot];
+  const LaunchSlot& sl = *ctx().last_slot;
   RT_HIP(hipStreamSynchronize(sl.stream));
   rt_stats s = sl.last;
   if (s.workgroups != 0) {
@@ -706,21 +843,27 @@ int rt_get_stats(rt_stats* out) {
     s.rays = c.rays;
     s.samples = c.samples;
     s.sphere_tests = c.rays * sl.last.sphere_tests;
-    float ms = 0.0f;
-    RT_HIP(hipEventElapsedTime(&ms, ctx().ev_begin[sl.event], ctx().ev_end[sl.event]));
-    s.kernel_ms = ms;
+    // the event pair of a launch is reused by the launch kEventRing launches later
+    s.kernel_ms = std::nanf("");
+    if (sl.launch_no != 0 && ctx().launches - sl.launch_no < (uint64_t)kEventRing) {
+      const int ev = (int)((sl.launch_no - 1) % kEventRing);
+      float ms = 0.0f;
+      RT_HIP(hipEventElapsedTime(&ms, ctx().ev_begin[ev], ctx().ev_end[ev]));
+      s.kernel_ms = ms;
+    }
   }
   *out = s;
   return RT_OK;
 }
 
 int rt_get_phase_cycles(uint64_t* out16) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
   if (!out16) return fail(RT_ERR_INVALID_ARGUMENT, "out16 is NULL");
   rt::Counters c;
   memset(&c, 0, sizeof c);
-  if (ctx().last_slot >= 0) {
-    const LaunchSlot& sl = ctx().slots[ctx().last_slot];
+  if (ctx().last_slot) {
+    const LaunchSlot& sl = *ctx().last_slot;
     RT_HIP(hipStreamSynchronize(sl.stream));
     RT_HIP(hipMemcpy(&c, sl.counters, sizeof c, hipMemcpyDeviceToHost));
   }
@@ -729,6 +872,7 @@ int rt_get_phase_cycles(uint64_t* out16) {
 }
 
 int rt_get_launch_ms(uint32_t n_last, float* out_ms) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
   if (n_last && !out_ms) return fail(RT_ERR_INVALID_ARGUMENT, "out_ms is NULL");
   uint64_t n = n_last;
@@ -744,125 +888,238 @@ int rt_get_launch_ms(uint32_t n_last, float* out_ms) {
   return (int)n;
 }
 
-int rt_render(const rt_request* req, float* out_rgb) {
-  if (int rc = check_ready()) return rc;
-  if (int rc = check_request(req, false)) return rc;
-  if (!out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
-  rt_frame f = frame_of(req);
-  if (int rc = check_frame(&f)) return rc;
-  ScopedScene sc;
-  if (int rc = rt_scene_create(req->spheres, req->n_spheres, req->materials, req->n_materials, &sc.s))
+namespace {
+
+// The device copy of the request's World on the context in charge: the one kept from the last
+// call when the request names the same spheres and materials, a fresh upload otherwise.
+int cached_scene(const rt_request* req, const rt_scene** out) {
+  FrameCache& fc = ctx().cache;
+  if (fc.scene && fc.scene->host_spheres.size() == req->n_spheres &&
+      fc.scene->host_materials.size() == req->n_materials &&
+      (req->n_spheres == 0 ||
+       memcmp(fc.scene->host_spheres.data(), req->spheres, req->n_spheres * sizeof(rt_sphere)) == 0) &&
+      (req->n_materials == 0 ||
+       memcmp(fc.scene->host_materials.data(), req->materials,
+              req->n_materials * sizeof(rt_material)) == 0)) {
+    *out = fc.scene;
+    return RT_OK;
+  }
+  if (fc.scene) {
+    RT_HIP(hipDeviceSynchronize());   // nothing may still be reading the old copy
+    (void)rt_scene_destroy(fc.scene);
+    fc.scene = nullptr;
+  }
+  if (int rc = rt_scene_create(req->spheres, req->n_spheres, req->materials, req->n_materials,
+                               &fc.scene))
     return rc;
-  const size_t bytes = (size_t)f.image_width * f.image_height * 3 * sizeof(float);
-  ScopedDev d;
-  RT_HIP(hipMalloc(&d.p, bytes));
-  if (int rc = rt_render_rows_device_async(sc.s, &f, 0, f.image_height, 1, (float*)d.p, ctx().stream))
-    return rc;
-  RT_HIP(hipStreamSynchronize(ctx().stream));
-  RT_HIP(hipMemcpy(out_rgb, d.p, bytes, hipMemcpyDeviceToHost));
+  *out = fc.scene;
   return RT_OK;
 }
 
-namespace {
-// Puts the primary context back in charge when a multi-device call leaves, however it leaves.
-struct ContextGuard {
-  ~ContextGuard() {
-    g_cur = &g_primary;
-    if (g_primary.ready) (void)hipSetDevice(g_primary.device);
+int cached_buffers(size_t floats) {
+  FrameCache& fc = ctx().cache;
+  if (floats > fc.frame_cap) {
+    RT_HIP(hipStreamSynchronize(ctx().stream));
+    if (fc.frame) RT_HIP(hipFree(fc.frame));
+    fc.frame = nullptr;
+    fc.frame_cap = 0;
+    RT_HIP(hipMalloc((void**)&fc.frame, floats * sizeof(float)));
+    fc.frame_cap = floats;
+  }
+  if (floats > fc.pinned_cap) {
+    RT_HIP(hipStreamSynchronize(ctx().stream));
+    if (fc.pinned) RT_HIP(hipHostFree(fc.pinned));
+    fc.pinned = nullptr;
+    fc.pinned_cap = 0;
+    RT_HIP(hipHostMalloc((void**)&fc.pinned, floats * sizeof(float), hipHostMallocDefault));
+    fc.pinned_cap = floats;
+  }
+  return RT_OK;
+}
+
+// One device's part of a host-pointer render.  `tiles` address a compact buffer of `pixels`
+// pixels (out_offset / out_stride); `dst[i]` is where tile i's rows go in the caller's frame
+// (pixel index of its first pixel; rows there are image_width apart).
+struct Share {
+  std::vector<rt::TileDev> tiles;
+  std::vector<uint64_t> dst;
+  uint64_t pixels = 0;
+  void add(uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint32_t image_width) {
+    rt::TileDev t;
+    memset(&t, 0, sizeof t);
+    t.x = x; t.y = y; t.w = w; t.h = h;
+    t.first_pixel = (uint32_t)pixels;
+    t.out_stride = w;
+    t.out_offset = pixels;
+    pixels += (uint64_t)w * h;
+    tiles.push_back(t);
+    dst.push_back((uint64_t)y * image_width + x);
   }
 };
-}  // namespace
 
-int rt_render_multi(const rt_request* req, const int* devices, int n_devices, float* out_rgb) {
+// Enqueue a share on the context in charge: render (resolved) into the cached device buffer,
+// then copy it to the pinned buffer in kCopyChunks pieces, an event behind each.  Returns
+// without waiting, so several devices can be given their shares one after the other.
+int enqueue_share(const rt_request* req, const rt_frame& f, const Share& sh) {
+  if (sh.pixels == 0) return RT_OK;
+  const rt_scene* scene = nullptr;
+  if (int rc = cached_scene(req, &scene)) return rc;
+  if (int rc = cached_buffers((size_t)sh.pixels * 3)) return rc;
+  FrameCache& fc = ctx().cache;
+  if (int rc = render_tiles_device(scene, &f, sh.tiles.data(), sh.tiles.size(), sh.pixels, 1,
+                                   fc.frame, ctx().stream))
+    return rc;
+  const size_t total = (size_t)sh.pixels * 3;
+  for (int k = 0; k < kCopyChunks; ++k) {
+    const size_t b = total * k / kCopyChunks, e = total * (k + 1) / kCopyChunks;
+    if (e > b)
+      RT_HIP(hipMemcpyAsync(fc.pinned + b, fc.frame + b, (e - b) * sizeof(float),
+                            hipMemcpyDeviceToHost, ctx().stream));
+    RT_HIP(hipEventRecord(fc.copied[k], ctx().stream));
+  }
+  return RT_OK;
+}
+
+// Wait for the share's pieces as they arrive and scatter their tile rows into the caller's
+// frame (the copy of piece k+1 runs while piece k is scattered).
+int collect_share(const Share& sh, uint32_t image_width, float* out_rgb) {
+  if (sh.pixels == 0) return RT_OK;
+  FrameCache& fc = ctx().cache;
+  const size_t total = (size_t)sh.pixels * 3;
+  size_t ti = 0;        // tile being scattered
+  uint32_t row = 0;     // next row of that tile
+  for (int k = 0; k < kCopyChunks; ++k) {
+    RT_HIP(hipEventSynchronize(fc.copied[k]));
+    const size_t ready = total * (k + 1) / kCopyChunks;   // floats of the compact buffer on the host
+    while (ti < sh.tiles.size()) {
+      const rt::TileDev& t = sh.tiles[ti];
+      const size_t row_floats = (size_t)t.w * 3;
+      const size_t src = ((size_t)t.out_offset + (size_t)row * t.w) * 3;
+      if (src + row_floats > ready) break;
+      // consecutive rows of a full-width tile are contiguous on both sides: one memcpy
+      uint32_t rows = 1;
+      if (t.w == image_width) {
+        const size_t fit = (ready - src) / row_floats;
+        rows = (uint32_t)(fit < (size_t)(t.h - row) ? fit : (size_t)(t.h - row));
+      }
+      memcpy(out_rgb + ((size_t)sh.dst[ti] + (size_t)row * image_width) * 3, fc.pinned + src,
+             row_floats * rows * sizeof(float));
+      row += rows;
+      if (row == t.h) {
+        ++ti;
+        row = 0;
+      }
+    }
+  }
+  return RT_OK;
+}
+
+// Does the request's tile list cover every pixel of the image?  (Overlaps do not matter: a
+// pixel's value does not depend on the tile that renders it.)
+bool covers_frame(const rt_tile* tiles, uint32_t n, uint32_t w, uint32_t h) {
+  uint64_t area = 0;
+  for (uint32_t i = 0; i < n; ++i) area += (uint64_t)tiles[i].width * tiles[i].height;
+  if (area < (uint64_t)w * h) return false;
+  std::vector<uint8_t> seen((size_t)w * h, 0);
+  for (uint32_t i = 0; i < n; ++i)
+    for (uint32_t y = 0; y < tiles[i].height; ++y)
+      if (tiles[i].width)
+        memset(&seen[(size_t)(tiles[i].y + y) * w + tiles[i].x], 1, tiles[i].width);
+  return memchr(seen.data(), 0, seen.size()) == nullptr;
+}
+
+// Puts the primary context back in charge when a multi-device call leaves, however it leaves.
+struct ContextGuard {
+  ~ContextGuard() { g_cur = &g_primary; }
+};
+
+// rt_render and rt_render_multi.  devices == nullptr: the primary context renders everything.
+int render_host(const rt_request* req, const int* devices, int n_devices, float* out_rgb) {
   if (int rc = check_ready()) return rc;
-  if (int rc = check_request(req, false)) return rc;
+  if (int rc = check_request(req, true)) return rc;
   if (!out_rgb) return fail(RT_ERR_INVALID_ARGUMENT, "out_rgb is NULL");
-  if (!devices || n_devices < 1 || n_devices > 64)
-    return fail(RT_ERR_INVALID_ARGUMENT, "device list of %d entries", n_devices);
   rt_frame f = frame_of(req);
   if (int rc = check_frame(&f)) return rc;
   const uint32_t W = f.image_width, H = f.image_height;
+  // The reference renders exactly the queued tiles and leaves every other pixel (0,0,0)
+  // (src/cpu/mod.rs:57-80).  No tile list, or one that covers the image, is the whole frame.
+  const bool listed = req->tiles != nullptr && req->n_tiles != 0;
+  if (listed)
+    if (int rc = check_tiles(req->tiles, req->n_tiles, W, H)) return rc;
+  const bool whole = !listed || covers_frame(req->tiles, req->n_tiles, W, H);
+  if (!whole) memset(out_rgb, 0, (size_t)W * H * 3 * sizeof(float));
+
   constexpr uint32_t kBlockRows = 8;   // rows are dealt to the devices in blocks of 8, round-robin
-  const uint32_t n_blocks = (H + kBlockRows - 1) / kBlockRows;
-
-  struct Share {
-    ScopedScene scene;
-    ScopedDev buffer;
-    std::vector<rt::TileDev> tiles;
-    uint64_t pixels = 0;
-  };
-  std::vector<Share> shares(n_devices);
-  ContextGuard guard;
-
-  // enqueue every device's share; nothing below waits, so the GPUs run side by side
-  for (int k = 0; k < n_devices; ++k) {
-    while ((int)g_extra.size() <= k) g_extra.push_back(new State());
-    g_cur = g_extra[k];
-    if (ctx().ready && ctx().device != devices[k]) destroy_context();
-    if (!ctx().ready)
-      if (int rc = init_context(devices[k])) return rc;
-    RT_HIP(hipSetDevice(ctx().device));
-    Share& sh = shares[k];
-    for (uint32_t b = (uint32_t)k; b < n_blocks; b += (uint32_t)n_devices) {
-      rt::TileDev t;
-      memset(&t, 0, sizeof t);
-      t.x = 0;
-      t.y = b * kBlockRows;
-      t.w = W;
-      t.h = H - t.y < kBlockRows ? H - t.y : kBlockRows;
-      t.first_pixel = (uint32_t)sh.pixels;
-      t.out_stride = W;
-      t.out_offset = sh.pixels;
-      sh.pixels += (uint64_t)t.w * t.h;
-      sh.tiles.push_back(t);
+  const int n = devices ? n_devices : 1;
+  std::vector<Share> shares(n);
+  if (!devices) {
+    if (whole) {
+      shares[0].add(0, 0, W, H, W);
+    } else {
+      for (uint32_t i = 0; i < req->n_tiles; ++i)
+        if (req->tiles[i].width && req->tiles[i].height)
+          shares[0].add(req->tiles[i].x, req->tiles[i].y, req->tiles[i].width, req->tiles[i].height, W);
     }
-    if (sh.tiles.empty()) continue;
-    if (int rc = rt_scene_create(req->spheres, req->n_spheres, req->materials, req->n_materials,
-                                 &sh.scene.s))
-      return rc;
-    RT_HIP(hipMalloc(&sh.buffer.p, sh.pixels * 3 * sizeof(float)));
-    if (int rc = render_tiles_device(sh.scene.s, &f, sh.tiles, sh.pixels, 1, (float*)sh.buffer.p,
-                                     ctx().stream))
-      return rc;
+  } else if (whole) {
+    const uint32_t n_blocks = (H + kBlockRows - 1) / kBlockRows;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+      const uint32_t y = b * kBlockRows;
+      shares[b % n].add(0, y, W, H - y < kBlockRows ? H - y : kBlockRows, W);
+    }
+  } else {
+    // a partial queue: every tile is cut along the same 8-row blocks, each piece going to the
+    // device that owns its block
+    for (uint32_t i = 0; i < req->n_tiles; ++i) {
+      const rt_tile& t = req->tiles[i];
+      if (!t.width || !t.height) continue;
+      for (uint32_t y = t.y; y < t.y + t.height;) {
+        const uint32_t b = y / kBlockRows;
+        uint32_t end = (b + 1) * kBlockRows;
+        if (end > t.y + t.height) end = t.y + t.height;
+        shares[b % n].add(t.x, y, t.width, end - y, W);
+        y = end;
+      }
+    }
   }
-  // collect: each share's blocks go to their rows of the caller's framebuffer
-  std::vector<float> staging;
-  for (int k = 0; k < n_devices; ++k) {
-    Share& sh = shares[k];
-    if (sh.tiles.empty()) continue;
-    g_cur = g_extra[k];
+
+  ContextGuard guard;
+  // enqueue every device's share; nothing in this loop waits, so the GPUs run side by side
+  for (int k = 0; k < n; ++k) {
+    if (devices) {
+      while ((int)g_extra.size() <= k) g_extra.push_back(new State());
+      g_cur = g_extra[k];
+      if (ctx().ready && ctx().device != devices[k]) destroy_context();
+      if (!ctx().ready)
+        if (int rc = init_context(devices[k])) return rc;
+    }
     RT_HIP(hipSetDevice(ctx().device));
-    RT_HIP(hipStreamSynchronize(ctx().stream));
-    staging.resize(sh.pixels * 3);
-    RT_HIP(hipMemcpy(staging.data(), sh.buffer.p, sh.pixels * 3 * sizeof(float),
-                     hipMemcpyDeviceToHost));
-    for (const rt::TileDev& t : sh.tiles)
-      memcpy(out_rgb + (size_t)t.y * W * 3, staging.data() + t.out_offset * 3,
-             (size_t)t.w * t.h * 3 * sizeof(float));
-    // free this device's buffers while its context is the one in charge
-    RT_HIP(hipFree(sh.buffer.p));
-    sh.buffer.p = nullptr;
-    (void)rt_scene_destroy(sh.scene.s);
-    sh.scene.s = nullptr;
+    if (int rc = enqueue_share(req, f, shares[k])) return rc;
+  }
+  for (int k = 0; k < n; ++k) {
+    if (devices) g_cur = g_extra[k];
+    RT_HIP(hipSetDevice(ctx().device));
+    if (int rc = collect_share(shares[k], W, out_rgb)) return rc;
   }
   return RT_OK;
+}
+
+}  // namespace
+
+int rt_render(const rt_request* req, float* out_rgb) {
+  ApiScope scope;
+  return render_host(req, nullptr, 0, out_rgb);
+}
+
+int rt_render_multi(const rt_request* req, const int* devices, int n_devices, float* out_rgb) {
+  ApiScope scope;
+  if (!devices || n_devices < 1 || n_devices > 64)
+    return fail(RT_ERR_INVALID_ARGUMENT, "device list of %d entries", n_devices);
+  return render_host(req, devices, n_devices, out_rgb);
 }
 
 namespace {
 // rt_render_tiles, and rt_accumulate_tiles when `inout` (the sums are uploaded first and the
 // call adds samples [sample_begin, sample_begin + spp) to them).
-int render_tiles_host(const rt_request* req, float* out_sums, bool inout, uint32_t sample_begin);
-}  // namespace
-
-int rt_render_tiles(const rt_request* req, float* out_sums) {
-  return render_tiles_host(req, out_sums, false, 0);
-}
-
-int rt_accumulate_tiles(const rt_request* req, uint32_t sample_begin, float* inout_sums) {
-  return render_tiles_host(req, inout_sums, true, sample_begin);
-}
-
-namespace {
 int render_tiles_host(const rt_request* req, float* out_sums, bool inout, uint32_t sample_begin) {
   if (int rc = check_ready()) return rc;
   if (int rc = check_request(req, true)) return rc;
@@ -879,26 +1136,35 @@ int render_tiles_host(const rt_request* req, float* out_sums, bool inout, uint32
     total += (uint64_t)req->tiles[i].width * req->tiles[i].height;
   }
   if (total == 0) return RT_OK;
-  ScopedScene sc;
-  if (int rc = rt_scene_create(req->spheres, req->n_spheres, req->materials, req->n_materials, &sc.s))
-    return rc;
+  const rt_scene* scene = nullptr;
+  if (int rc = cached_scene(req, &scene)) return rc;
   const size_t bytes = (size_t)total * 3 * sizeof(float);
-  ScopedDev d;
-  RT_HIP(hipMalloc(&d.p, bytes));
+  if (int rc = cached_buffers((size_t)total * 3)) return rc;
+  float* d = ctx().cache.frame;
   if (inout) {
-    RT_HIP(hipMemcpy(d.p, out_sums, bytes, hipMemcpyHostToDevice));
-    if (int rc = rt_accumulate_device_async(sc.s, &f, sample_begin, req->tiles, off.data(),
-                                            stride.data(), req->n_tiles, (float*)d.p, ctx().stream))
+    RT_HIP(hipMemcpyAsync(d, out_sums, bytes, hipMemcpyHostToDevice, ctx().stream));
+    if (int rc = rt_accumulate_device_async(scene, &f, sample_begin, req->tiles, off.data(),
+                                            stride.data(), req->n_tiles, d, ctx().stream))
       return rc;
-  } else if (int rc = rt_render_device_async(sc.s, &f, req->tiles, off.data(), stride.data(),
-                                             req->n_tiles, 0, (float*)d.p, ctx().stream)) {
+  } else if (int rc = rt_render_device_async(scene, &f, req->tiles, off.data(), stride.data(),
+                                             req->n_tiles, 0, d, ctx().stream)) {
     return rc;
   }
+  RT_HIP(hipMemcpyAsync(out_sums, d, bytes, hipMemcpyDeviceToHost, ctx().stream));
   RT_HIP(hipStreamSynchronize(ctx().stream));
-  RT_HIP(hipMemcpy(out_sums, d.p, bytes, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 }  // namespace
+
+int rt_render_tiles(const rt_request* req, float* out_sums) {
+  ApiScope scope;
+  return render_tiles_host(req, out_sums, false, 0);
+}
+
+int rt_accumulate_tiles(const rt_request* req, uint32_t sample_begin, float* inout_sums) {
+  ApiScope scope;
+  return render_tiles_host(req, inout_sums, true, sample_begin);
+}
 
 int rt_compose(const rt_tile* tiles, uint32_t n_tiles, const float* tile_sums, uint32_t image_width,
                uint32_t image_height, uint32_t samples_per_pixel, float* out_rgb) {
@@ -931,10 +1197,21 @@ int rt_compose(const rt_tile* tiles, uint32_t n_tiles, const float* tile_sums, u
 
 int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays, uint32_t seed,
                   uint32_t flags, rt_ray_out* out) {
+  ApiScope scope;
   if (int rc = check_ready()) return rc;
   if (!scene) return fail(RT_ERR_INVALID_ARGUMENT, "scene is NULL");
   if (n_rays == 0) return RT_OK;
   if (!rays || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL rays or out");
+  if (scene->device != ctx().device)
+    return fail(RT_ERR_INVALID_ARGUMENT, "scene lives on device %d, the library on device %d",
+                scene->device, ctx().device);
+  const bool accel = (flags & RT_FLAG_ACCEL) != 0;
+  if (accel) {
+    if (int rc = ensure_bvh(scene)) return rc;
+    if (scene->bvh_depth > rt::bvh_stack_depth())
+      return fail(RT_ERR_LIMIT, "hierarchy of %u levels exceeds the traversal stack (%u)",
+                  scene->bvh_depth, rt::bvh_stack_depth());
+  }
   ScopedDev din, dout;
   RT_HIP(hipMalloc(&din.p, (size_t)n_rays * sizeof(rt_ray_in)));
   RT_HIP(hipMalloc(&dout.p, (size_t)n_rays * sizeof(rt_ray_out)));
@@ -945,10 +1222,7 @@ int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays,
   hp.out = (rt_ray_out*)dout.p;
   hp.n_rays = n_rays;
   hp.seed = seed;
-  hp.accel = (flags & RT_FLAG_ACCEL) != 0 ? 1 : 0;
-  if (hp.accel && scene->bvh_depth > rt::bvh_stack_depth())
-    return fail(RT_ERR_LIMIT, "hierarchy of %u levels exceeds the traversal stack (%u)",
-                scene->bvh_depth, rt::bvh_stack_depth());
+  hp.accel = accel ? 1 : 0;
   RT_HIP(rt::launch_hook(hp, (flags & RT_FLAG_STRICT_FP) != 0, ctx().stream));
   RT_HIP(hipStreamSynchronize(ctx().stream));
   RT_HIP(hipMemcpy(out, dout.p, (size_t)n_rays * sizeof(rt_ray_out), hipMemcpyDeviceToHost));

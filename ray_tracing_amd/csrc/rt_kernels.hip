@@ -1094,11 +1094,14 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
     const uint32_t ty = local / t.w;
     const uint32_t tx = local - ty * t.w;
     const uint64_t o = t.out_offset + (uint64_t)ty * t.out_stride + tx;
-    const float* src = p.partial + 3ull * o;
-    float r = src[0], gch = src[1], b = src[2];
-    for (uint32_t k = 1; k < p.slices; ++k) {
-      const float* pl = src + 3ull * k * p.out_pixels;
-      r += pl[0]; gch += pl[1]; b += pl[2];
+    float r = 0.0f, gch = 0.0f, b = 0.0f;   // slices == 0: the covered pixels are set to zero
+    if (p.slices != 0) {
+      const float* src = p.partial + 3ull * o;
+      r = src[0]; gch = src[1]; b = src[2];
+      for (uint32_t k = 1; k < p.slices; ++k) {
+        const float* pl = src + 3ull * k * p.out_pixels;
+        r += pl[0]; gch += pl[1]; b += pl[2];
+      }
     }
     float* dst = p.out + 3ull * o;
     if (p.accumulate) {
@@ -1124,6 +1127,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveParams p) {
 
 // Per-ray test hook: one World::hit and one scatter decision per input ray, through the same
 // scan / replay / shade code as the main kernel.  Path slot 0 of each lane carries the ray.
+// bvh_hit strides its LDS stack by kThreadsAccel; this kernel runs it in kThreads-wide workgroups.
+static_assert(kThreads == kThreadsAccel, "hook_kernel's traversal stack assumes equal workgroup sizes");
 template <bool STRICT>
 __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   extern __shared__ float4 lds[];

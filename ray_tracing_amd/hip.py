@@ -160,17 +160,21 @@ def make_request(spheres, materials, camera, width, height, spp, max_depth, seed
     return r, keep
 
 
-def render(spheres, materials, camera, width, height, spp, max_depth, seed, flags=0):
-    """rt_render: resolved framebuffer, shape (H, W, 3), row 0 = bottom of the picture."""
-    req, keep = make_request(spheres, materials, camera, width, height, spp, max_depth, seed, flags)
+def render(spheres, materials, camera, width, height, spp, max_depth, seed, flags=0, tiles=None):
+    """rt_render: resolved framebuffer, shape (H, W, 3), row 0 = bottom of the picture.  With
+    `tiles`, exactly those tiles are rendered and every other pixel is (0, 0, 0)."""
+    req, keep = make_request(spheres, materials, camera, width, height, spp, max_depth, seed, flags,
+                             tiles)
     out = np.empty((height, width, 3), dtype=np.float32)
     check(lib().rt_render(C.byref(req), abi.ptr(out)))
     return out
 
 
-def render_multi(spheres, materials, camera, width, height, spp, max_depth, seed, devices, flags=0):
+def render_multi(spheres, materials, camera, width, height, spp, max_depth, seed, devices, flags=0,
+                 tiles=None):
     """rt_render_multi: one process, several GPUs (a device may be listed more than once)."""
-    req, keep = make_request(spheres, materials, camera, width, height, spp, max_depth, seed, flags)
+    req, keep = make_request(spheres, materials, camera, width, height, spp, max_depth, seed, flags,
+                             tiles)
     dev = np.ascontiguousarray(devices, dtype=np.int32)
     out = np.empty((height, width, 3), dtype=np.float32)
     check(lib().rt_render_multi(C.byref(req), abi.ptr(dev), len(dev), abi.ptr(out)))

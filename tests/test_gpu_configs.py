@@ -1,0 +1,175 @@
+"""The benchmark configurations' own workloads on the GPU.
+
+ * the 10 004-sphere brute-force scene (the scan streams it through LDS in five chunks):
+   per-ray records and a small image against the oracle, bit for bit, then the full
+   1920x1080 @ 64 spp frame through properties that do not depend on size;
+ * 3840x2160 @ 500 spp: the frame's own sample-slice plan (body + taper), the eight row
+   shares of an 8-GPU run rendered one after the other and put back together, against the
+   frame rendered whole;
+ * the body + taper slice plan against the reference's sample order on one >= 2^20-pixel frame.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from ray_tracing_amd import abi, hip, host, multi_gpu
+from test_gpu_parity import FLOAT_FIELDS, INT_FIELDS, default_camera, make_rays, oracle_sums
+
+pytestmark = pytest.mark.gpu
+
+STRICT = abi.RT_FLAG_STRICT_FP
+SEQ = abi.RT_FLAG_SEQUENTIAL_SUM
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    hip.init(0)
+    yield
+
+
+@pytest.fixture(scope="module")
+def world10k():
+    s, m = O.random_world(1, -50, 50)
+    assert len(s) == 10004
+    return s, m
+
+
+def test_10k_brute_force_scan_per_ray_matches_world_hit(world10k):
+    """World::hit's loop over all 10 004 spheres (src/main.rs:175-189) as five LDS chunks with the
+    closest hit carried across them: every record field equals ro_bounce's, in the literal and
+    in the conservative scan."""
+    s, m = world10k
+    cam = default_camera()
+    rays = make_rays((s, m), cam, 700, seed=12)
+    assert len(rays) >= 600
+    ref = O.bounce(O.make_world(s, m), rays, seed=31, pow5_mode=O.RO_POW5_MUL)
+    scene = hip.Scene(s, m)
+    for flags in (STRICT, 0):
+        got = hip.trace_rays(scene, rays, seed=31, flags=flags)
+        for f in INT_FIELDS:
+            assert np.array_equal(got[f], ref[f]), (flags, f)
+        for f in FLOAT_FIELDS:
+            assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), (flags, f)
+    # hits spread over all five chunks of 2016 spheres
+    hit = ref["sphere"][ref["hit"] == 1]
+    assert set(np.unique(hit // 2016)) == {0, 1, 2, 3, 4}
+    scene.close()
+
+
+def test_10k_brute_force_image_matches_the_oracle(world10k):
+    s, m = world10k
+    w, h, spp = 48, 27, 2
+    cam = default_camera(w / h)
+    tiles = O.job_queue(w, h, 64, 64)
+    _, ref, ctr = oracle_sums(s, m, cam, w, h, spp, 50, 2, tiles)
+    for flags in (SEQ, SEQ | STRICT):
+        sums = hip.render_tiles(s, m, cam, w, h, spp, 50, 2, tiles, flags=flags)
+        assert np.array_equal(sums.view(np.uint32), ref.view(np.uint32)), flags
+        st = hip.get_stats()
+        assert (st.rays, st.samples) == (ctr.rays, ctr.samples)
+        assert st.sphere_tests == ctr.rays * 10004
+        assert st.threads_per_workgroup == 512          # the chunked kernel
+
+
+def test_10k_brute_force_full_size_frame_properties():
+    """1920x1080 @ 64 spp on the chunked scan (what the benchmark's 10k configuration runs):
+    determinism, counters, resolve range, and a strip rendered alone equals its rows."""
+    w, h, spp = 1920, 1080, 64
+    world = host.create_random_world(1, (-50, 50))
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
+    scene = hip.Scene(world.spheres, world.materials)
+    frame = hip.make_frame(camera.m, w, h, spp, 50, 1, flags=0)
+    stream = torch.cuda.current_stream().cuda_stream
+    a = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    b = torch.zeros_like(a)
+    hip.render_rows_device_async(scene, frame, 0, h, True, a.data_ptr(), stream)
+    torch.cuda.synchronize()
+    st = hip.get_stats()
+    assert st.samples == w * h * spp and st.rays >= st.samples
+    assert st.sphere_tests == st.rays * 10004 and st.threads_per_workgroup == 512
+    hip.render_rows_device_async(scene, frame, 0, h, True, b.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    strip = torch.zeros((8, w, 3), dtype=torch.float32, device="cuda:0")
+    hip.render_rows_device_async(scene, frame, 300, 308, True, strip.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(strip.view(torch.int32), a[300:308].view(torch.int32))
+    img = a.cpu().numpy()
+    ok = ~np.isnan(img)
+    assert img[ok].min() >= 0.0 and img[ok].max() <= np.float32(0.999)
+    assert np.all(img[-1, :, 2] == np.float32(0.999))
+    scene.close()
+
+
+def test_4k_500spp_eight_row_shares_reassemble_to_the_whole_frame():
+    """3840x2160 @ 500 spp (54 slices of 9 samples and a taper of 8): the frame rendered whole,
+    then as the eight shares RowPlan deals to 8 GPUs, one after the other on this GPU through the
+    entry point the ranks use, reassembled with the plan's row map: the same bits, the same
+    counters."""
+    w, h, spp = 3840, 2160, 500
+    world = host.create_random_world(1, (-11, 11))
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
+    scene = hip.Scene(world.spheres, world.materials)
+    frame = hip.make_frame(camera.m, w, h, spp, 50, 1, flags=0)
+    stream = torch.cuda.current_stream().cuda_stream
+    full = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    hip.render_rows_device_async(scene, frame, 0, h, True, full.data_ptr(), stream)
+    torch.cuda.synchronize()
+    st = hip.get_stats()
+    assert st.samples == w * h * spp and st.slices == 62
+    total_rays = st.rays
+    plan = multi_gpu.RowPlan(w, h, 8)
+    stacked = torch.zeros((8, plan.rows_per_rank, w, 3), dtype=torch.float32, device="cuda:0")
+    rays = 0
+    for rank in range(8):
+        tiles, offs, strides = plan.tiles_for(rank)
+        hip.render_device_async(scene, frame, tiles, offs, strides, True, stacked[rank].data_ptr(),
+                                stream)
+        torch.cuda.synchronize()
+        s = hip.get_stats()
+        assert s.samples == plan.rows_of(rank) * w * spp
+        rays += s.rays
+    assert rays == total_rays
+    row_map = torch.from_numpy(plan.frame_row_map()).to("cuda:0")
+    again = stacked.reshape(-1, w, 3).index_select(0, row_map)
+    assert torch.equal(again.view(torch.int32), full.view(torch.int32))
+    # and the whole frame reproduces itself
+    hip.render_rows_device_async(scene, frame, 0, h, True, again.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(again.view(torch.int32), full.view(torch.int32))
+    scene.close()
+
+
+def test_body_and_taper_slices_agree_with_the_reference_sample_order():
+    """A frame of more than 2^20 pixels whose samples are cut into full-size items plus the
+    tapered tail (4,4,2,2,1,1,1,1), against the same frame with every pixel's samples added in
+    the reference's order (`pixel_color += color`, src/cpu/job.rs:58).  The paths are the same
+    (equal ray counts), so the two sums of n = 300 floats differ only by the association of the
+    additions: each is within (n-1) u of the exact sum relative to the sum of magnitudes
+    (u = 2^-24), so they are within 2 n u = 3.6e-5 of each other; the test prints what it finds."""
+    w, h, spp = 1920, 1080, 300
+    world = host.create_random_world(1, (-11, 11))
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
+    scene = hip.Scene(world.spheres, world.materials)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for name, flags in (("sliced", 0), ("sequential", SEQ)):
+        out = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+        frame = hip.make_frame(camera.m, w, h, spp, 50, 1, flags=flags)
+        hip.render_rows_device_async(scene, frame, 0, h, False, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        st = hip.get_stats()
+        outs[name] = (out.cpu().numpy().astype(np.float64), st)
+    (a, st_a), (b, st_b) = outs["sliced"], outs["sequential"]
+    assert st_a.slices == 56 and st_b.slices == 1          # 48 items of 6 samples + the taper of 8
+    assert (st_a.rays, st_a.samples) == (st_b.rays, st_b.samples)
+    # relative to the magnitude of what was added up (at least 1: a pixel whose negative-albedo
+    # samples cancel has a small sum of larger terms)
+    scale = np.maximum(np.abs(b), 1.0)
+    err = np.abs(a - b) / scale
+    print("sliced vs sequential sums, relative difference: max %.3g, median %.3g, 99.9%% %.3g"
+          % (err.max(), np.median(err), np.quantile(err, 0.999)))
+    assert err.max() <= 2 * spp * 2.0 ** -24
+    assert np.median(err) <= 2e-6
+    scene.close()

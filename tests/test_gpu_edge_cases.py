@@ -61,3 +61,30 @@ def test_max_depth_one_and_two():
     s, m = O.random_world(1, -4, 4)
     for depth in (1, 2):
         check(s, m, 32, 18, 3, depth=depth)
+
+
+def test_depth_zero_writes_only_the_pixels_its_tiles_cover():
+    """Two calls share one buffer at interleaved row blocks (what a rank's blocks look like at
+    full-frame offsets).  shoot_ray(ray, 0) is black (src/main.rs:192-194), so a call at
+    max_depth 0 sets ITS rows to zero; the rows between them belong to someone else."""
+    import torch
+    w, h = 32, 16
+    s, m = O.random_world(1, -4, 4)
+    scene = hip.Scene(s, m)
+    cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, w / h)
+    out = torch.full((h, w, 3), 5.0, dtype=torch.float32, device="cuda:0")
+    tiles = np.array([(0, 0, w, 4), (0, 8, w, 4)], dtype=abi.TILE_DTYPE)
+    offs = np.array([0, 8 * w], dtype=np.uint64)
+    strides = np.full(2, w, dtype=np.uint32)
+    stream = torch.cuda.current_stream().cuda_stream
+    for resolve in (False, True):
+        out.fill_(5.0)
+        for flags in (0, SEQ):
+            frame = hip.make_frame(cam, w, h, 4, 0, 1, flags)
+            hip.render_device_async(scene, frame, tiles, offs, strides, resolve, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.all(got[0:4] == 0.0) and np.all(got[8:12] == 0.0)
+        assert np.all(got[4:8] == 5.0) and np.all(got[12:16] == 5.0)
+        assert hip.get_stats().samples == 2 * 4 * w * 4
+    scene.close()

@@ -311,6 +311,42 @@ def test_host_mirror_dispatch_work_gpu_matches_the_reference_contract():
     assert fb[ok].min() >= 0.0 and fb[ok].max() <= np.float32(0.999)
 
 
+def test_dispatch_work_gpu_renders_exactly_the_queued_tiles():
+    """The reference renders the tiles in the Dispatch's queue and leaves every pixel no tile
+    covers at (0,0,0) (src/cpu/mod.rs:57-80); a tile outside the image makes it panic
+    (index out of bounds at src/cpu/mod.rs:78)."""
+    from ray_tracing_amd import host
+    w, h, spp, depth = 96, 54, 3, 50
+    world = host.create_random_world(1, (-4, 4))
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
+    queue = host.create_job_queue(w, h, 32, 32)
+    part = queue[[0, 2, 3, 5]]                       # a few tiles of the queue, ragged ones among them
+    extra = np.array([(40, 20, 13, 30)], dtype=abi.TILE_DTYPE)   # overlaps two of them, crosses row blocks
+    part = np.concatenate([part, extra])
+    ref_fb, _, _ = oracle_sums(world.spheres, world.materials, camera.m, w, h, spp, depth, 13, part)
+    covered = np.zeros((h, w), dtype=bool)
+    for t in part:
+        covered[t["y"]:t["y"] + t["height"], t["x"]:t["x"] + t["width"]] = True
+    assert covered.any() and not covered.all()
+    fb = host.dispatch_work_gpu(host.Dispatch.new(part, w, h, depth, spp, camera, world), 1,
+                                seed=13, flags=STRICT | SEQ)
+    assert np.all(fb[~covered] == 0.0)
+    assert np.array_equal(fb.view(np.uint32), ref_fb.view(np.uint32))
+    # the same queue shared by several devices of one process
+    many = hip.render_multi(world.spheres, world.materials, camera.m, w, h, spp, depth, 13,
+                            [0, 0, 0], flags=STRICT | SEQ, tiles=part)
+    assert np.array_equal(many.view(np.uint32), ref_fb.view(np.uint32))
+    # a full cover given as tiles is the whole frame
+    whole = hip.render(world.spheres, world.materials, camera.m, w, h, spp, depth, 13,
+                       flags=STRICT | SEQ, tiles=queue)
+    full_ref, _, _ = oracle_sums(world.spheres, world.materials, camera.m, w, h, spp, depth, 13, queue)
+    assert np.array_equal(whole.view(np.uint32), full_ref.view(np.uint32))
+    outside = np.array([(80, 40, 32, 32)], dtype=abi.TILE_DTYPE)
+    with pytest.raises(host.HostError) as e:
+        host.dispatch_work_gpu(host.Dispatch.new(outside, w, h, depth, spp, camera, world), 1, seed=13)
+    assert "leaves the 96x54 image" in str(e.value)
+
+
 def test_full_size_frame_properties():
     """At the benchmark's full size the oracle is too slow to compare against; check what does
     not depend on size: determinism, the ray/sample counters, the resolve range, and that a
