@@ -11,7 +11,7 @@
  *    available from rt_last_error() (thread-local).  Nothing aborts and nothing throws.
  *  - the caller owns every buffer it passes; the library keeps no pointer after a call returns
  *    (rt_scene objects own their own device copies).
- *  - calls are blocking unless the name ends in _async.  The library keeps one set
+ *  - calls are blocking unless the name ends in _async or _noalloc.  The library keeps one set
  *    of contexts per process behind one lock: calls from several host threads are serialised,
  *    never concurrent.  Every call leaves the calling thread's current HIP device as it found it.
  *  - results are a pure function of (seed, scene, camera, W, H, spp, max_depth, flags): they do
@@ -255,6 +255,24 @@ int rt_accumulate_device_async(const rt_scene* scene, const rt_frame* frame, uin
  * n_pixels RGB sums in device memory; d_rgb may be d_sums. */
 int rt_resolve_device_async(const float* d_sums, uint64_t n_pixels, uint32_t samples_per_pixel,
                             float* d_rgb, void* stream);
+
+/* rt_render_rows_device_async for callers that cannot allocate: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.
+ * Same arguments, same pixels (bit for bit), but the call never allocates, frees or waits: its
+ * work counters and the partial sums of sliced samples live in one fixed device buffer that the
+ * library holds on every GPU it runs on from load to exit (RT_NOALLOC_PLANE_BYTES of planes).
+ * Limits: the rows of one call times the frame's sample slices must fit that buffer
+ *   (row_end - row_begin) * image_width * slices * 12 bytes <= RT_NOALLOC_PLANE_BYTES
+ * (RT_FLAG_SEQUENTIAL_SUM has one slice and needs no planes at all, so any size passes); a
+ * request beyond it fails with RT_ERR_LIMIT and a message that says by how much.  RT_FLAG_ACCEL
+ * is accepted only for a scene whose hierarchy an allocating call has already built.
+ * Every call on a GPU shares that GPU's buffer: two calls that overlap on one GPU (different
+ * streams, or different host threads' streams) RACE; calls on one stream, or otherwise ordered,
+ * are fine.  The counters are cleared by each call. */
+#define RT_NOALLOC_PLANE_BYTES (64u << 20)
+int rt_render_rows_device_noalloc(const rt_scene* scene, const rt_frame* frame,
+                                  uint32_t row_begin, uint32_t row_end,
+                                  int resolve, float* d_out, void* stream);
 
 int rt_synchronize(void* stream);
 int rt_get_stats(rt_stats* out);

@@ -40,6 +40,17 @@ struct rt_scene {
 
 namespace {
 
+// ---- memory for rt_render_rows_device_noalloc ------------------------------------------------
+// Work counters and partial-sum planes of the entry point that may not allocate.  Every GPU the
+// library runs on holds its own copy of this array, at its own address, from the moment the
+// code object is loaded until the process ends.  In host code the NAME below is only a handle
+// for hipGetSymbolAddress (init_context asks once per device and keeps the answer in
+// State::scratch); it is never passed to a kernel, a memset or a copy.
+constexpr size_t kScratchCounterBytes = 256;                  // rt::Counters, padded
+constexpr size_t kScratchPlaneBytes = RT_NOALLOC_PLANE_BYTES; // partial-sum planes
+static __device__ __align__(256) unsigned char scratch[kScratchCounterBytes + kScratchPlaneBytes];
+static_assert(sizeof(rt::Counters) <= kScratchCounterBytes, "counters must fit their slot");
+
 thread_local std::string g_error;
 
 int fail(int code, const char* fmt, ...) {
@@ -72,8 +83,8 @@ struct LaunchSlot {
   hipStream_t stream = nullptr;
   bool bound = false;
   rt::Counters* counters = nullptr;       // device
-  float* partial = nullptr;               // device, grow-only: per-slice sums
-  size_t partial_cap = 0;                 // in floats
+  float* partial = nullptr;               // device: per-slice sums (grow-only; fixed for the
+  size_t partial_cap = 0;                 // no-alloc slot), capacity in floats
   uint64_t last_use = 0;
   rt_stats last = {};
   uint64_t launch_no = 0;                 // 1-based number of the slot's last launch; 0 = none
@@ -98,6 +109,8 @@ struct State {
   int cus = 0;
   hipStream_t stream = nullptr;
   LaunchSlot slots[kLaunchSlots];
+  LaunchSlot noalloc_slot;                // counters and planes inside `scratch`
+  void* scratch = nullptr;                // this device's address of `scratch`
   LaunchSlot* last_slot = nullptr;
   rt::TileDev* tiles = nullptr;           // device, grow-only
   size_t tiles_cap = 0;
@@ -328,9 +341,12 @@ int blocks_per_cu(bool strict, bool multi, bool accel, size_t lds, int* out) {
 
 // `sample_begin` / `accumulate`: the call adds samples [sample_begin, sample_begin + spp) of
 // every pixel to what d_out already holds (progressive rendering; resolve must be 0).
+// `no_alloc`: the call may not allocate, free or wait; its counters and partial planes are the
+// fixed ones in `scratch`, and a request they cannot hold is refused.
 int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::TileDev* tiles,
                         size_t n_tiles, uint64_t out_pixels, int resolve, float* d_out,
-                        hipStream_t stream, uint32_t sample_begin = 0, bool accumulate = false) {
+                        hipStream_t stream, uint32_t sample_begin = 0, bool accumulate = false,
+                        bool no_alloc = false) {
   rt::TraceParams p;
   memset(&p, 0, sizeof p);
   p.cam = frame->camera;
@@ -369,6 +385,10 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   const bool strict = (frame->flags & RT_FLAG_STRICT_FP) != 0;
   const bool accel = (frame->flags & RT_FLAG_ACCEL) != 0;
   if (accel) {
+    if (no_alloc && !scene->bvh_built)
+      return fail(RT_ERR_INVALID_ARGUMENT,
+                  "RT_FLAG_ACCEL: the scene's hierarchy has not been built yet, and this entry "
+                  "point may not allocate it (render once through rt_render_rows_device_async)");
     if (int rc = ensure_bvh(scene)) return rc;
     if (scene->bvh_depth > rt::bvh_stack_depth())
       return fail(RT_ERR_LIMIT, "hierarchy of %u levels exceeds the traversal stack (%u)",
@@ -378,7 +398,21 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
 
   const size_t partial_need = p.slices > 1 ? (size_t)out_pixels * 3 * p.slices : 0;
   LaunchSlot* slot = nullptr;
-  if (int rc = acquire_slot(stream, &slot)) return rc;
+  if (no_alloc) {
+    slot = &ctx().noalloc_slot;
+    if (n_tiles != 1) return fail(RT_ERR_INVALID_ARGUMENT, "one tile per call");
+    if (partial_need > slot->partial_cap)
+      return fail(RT_ERR_LIMIT,
+                  "%llu pixels x %u sample slices need %zu bytes of partial sums; the fixed buffer "
+                  "of this entry point holds %zu (render fewer rows per call, or set "
+                  "RT_FLAG_SEQUENTIAL_SUM, which needs none)",
+                  (unsigned long long)out_pixels, p.slices, partial_need * sizeof(float),
+                  slot->partial_cap * sizeof(float));
+    slot->stream = stream;
+    slot->last_use = ctx().launches + 1;
+  } else if (int rc = acquire_slot(stream, &slot)) {
+    return rc;
+  }
   p.counters = slot->counters;
 
   if (n_tiles == 1) {
@@ -435,7 +469,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
 
   float* trace_out = d_out;
   if (p.slices > 1) {
-    if (partial_need > slot->partial_cap) {
+    if (partial_need > slot->partial_cap) {   // never true for the fixed slot (checked above)
       RT_HIP(hipStreamSynchronize(stream));   // the slot's earlier launches read the old buffer
       if (slot->partial) RT_HIP(hipFree(slot->partial));
       slot->partial = nullptr;
@@ -561,6 +595,17 @@ int init_context(int device) {
     RT_HIP(hipMalloc((void**)&sl.counters, sizeof(rt::Counters)));
     RT_HIP(hipMemset(sl.counters, 0, sizeof(rt::Counters)));
   }
+  // This device's copy of `scratch`: asked for once, with the device current, and used through
+  // the returned address from here on.
+  void* base = nullptr;
+  RT_HIP(hipGetSymbolAddress(&base, HIP_SYMBOL(scratch)));
+  ctx().scratch = base;
+  LaunchSlot& na = ctx().noalloc_slot;
+  na = LaunchSlot();
+  na.bound = true;
+  na.counters = reinterpret_cast<rt::Counters*>(base);
+  na.partial = reinterpret_cast<float*>(static_cast<unsigned char*>(base) + kScratchCounterBytes);
+  na.partial_cap = kScratchPlaneBytes / sizeof(float);
   for (int i = 0; i < kEventRing; ++i) {
     RT_HIP(hipEventCreate(&ctx().ev_begin[i]));
     RT_HIP(hipEventCreate(&ctx().ev_end[i]));
@@ -817,6 +862,20 @@ int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame, ui
   const rt::TileDev t = rows_tile(frame, row_begin, row_end);
   hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
   return render_tiles_device(scene, frame, &t, 1, (uint64_t)t.w * t.h, resolve, d_out, s);
+}
+
+int rt_render_rows_device_noalloc(const rt_scene* scene, const rt_frame* frame, uint32_t row_begin,
+                                  uint32_t row_end, int resolve, float* d_out, void* stream) {
+  ApiScope scope;
+  if (int rc = check_ready()) return rc;
+  if (int rc = check_rows(scene, frame, row_begin, row_end)) return rc;
+  if (row_begin == row_end) return RT_OK;
+  if (!d_out) return fail(RT_ERR_INVALID_ARGUMENT, "d_out is NULL");
+  if (!ctx().scratch) return fail(RT_ERR_NOT_INITIALIZED, "the fixed buffer has no address");
+  const rt::TileDev t = rows_tile(frame, row_begin, row_end);
+  hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
+  return render_tiles_device(scene, frame, &t, 1, (uint64_t)t.w * t.h, resolve, d_out, s, 0, false,
+                             /*no_alloc=*/true);
 }
 
 int rt_synchronize(void* stream) {

@@ -22,7 +22,7 @@ EXPORTS = (
     "rt_init", "rt_shutdown", "rt_last_error", "rt_abi_version",
     "rt_render", "rt_render_multi", "rt_render_tiles", "rt_accumulate_tiles", "rt_compose",
     "rt_scene_create", "rt_scene_destroy",
-    "rt_render_device_async", "rt_render_rows_device_async",
+    "rt_render_device_async", "rt_render_rows_device_async", "rt_render_rows_device_noalloc",
     "rt_accumulate_device_async", "rt_resolve_device_async",
     "rt_synchronize", "rt_get_stats", "rt_get_launch_ms", "rt_get_phase_cycles", "rt_trace_rays",
 )
@@ -83,6 +83,7 @@ def lib():
     L.rt_scene_destroy.argtypes = [vp]
     L.rt_render_device_async.argtypes = [vp, C.POINTER(abi.RtFrame), vp, vp, vp, u32, i, vp, vp]
     L.rt_render_rows_device_async.argtypes = [vp, C.POINTER(abi.RtFrame), u32, u32, i, vp, vp]
+    L.rt_render_rows_device_noalloc.argtypes = [vp, C.POINTER(abi.RtFrame), u32, u32, i, vp, vp]
     L.rt_accumulate_device_async.argtypes = [vp, C.POINTER(abi.RtFrame), u32, vp, vp, vp, u32, vp, vp]
     L.rt_resolve_device_async.argtypes = [vp, u64, u32, vp, vp]
     L.rt_synchronize.argtypes = [vp]
@@ -215,6 +216,14 @@ def render_rows_device_async(scene, frame, row_begin, row_end, resolve, d_out_pt
     check(lib().rt_render_rows_device_async(scene.handle, C.byref(frame), int(row_begin),
                                             int(row_end), int(bool(resolve)),
                                             C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr or 0)))
+
+
+def render_rows_device_noalloc(scene, frame, row_begin, row_end, resolve, d_out_ptr, stream_ptr=None):
+    """rt_render_rows_device_noalloc: the same rows, with counters and partial sums in the
+    library's fixed device buffer (no allocation, no wait)."""
+    check(lib().rt_render_rows_device_noalloc(scene.handle, C.byref(frame), int(row_begin),
+                                              int(row_end), int(bool(resolve)),
+                                              C.c_void_p(d_out_ptr), C.c_void_p(stream_ptr or 0)))
 
 
 def render_device_async(scene, frame, tiles, out_offset, out_stride, resolve, d_out_ptr,

@@ -1,0 +1,85 @@
+"""rt_render_rows_device_noalloc against rt_render_rows_device_async, through the C ABI.
+
+The entry point that may not allocate keeps its work counters and the partial sums of sliced
+samples in one fixed device buffer of the library.  It must give the allocating entry point's
+pixels bit for bit, on calls that follow each other (the second smaller than the first, so
+that anything the first call left in the buffer would show), and refuse what the buffer cannot
+hold."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from ray_tracing_amd import abi, hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    hip.init(0)
+    yield
+
+
+def both(scene, cam, w, h, spp, flags, rows=None, resolve=True, seed=3, depth=50):
+    r0, r1 = rows or (0, h)
+    frame = hip.make_frame(cam, w, h, spp, depth, seed, flags)
+    stream = torch.cuda.current_stream().cuda_stream
+    ref = torch.full((r1 - r0, w, 3), -7.0, dtype=torch.float32, device="cuda:0")
+    got = torch.full_like(ref, -9.0)
+    hip.render_rows_device_async(scene, frame, r0, r1, resolve, ref.data_ptr(), stream)
+    torch.cuda.synchronize()
+    st_ref = hip.get_stats()
+    hip.render_rows_device_noalloc(scene, frame, r0, r1, resolve, got.data_ptr(), stream)
+    torch.cuda.synchronize()
+    st = hip.get_stats()
+    assert (st.rays, st.samples, st.slices) == (st_ref.rays, st_ref.samples, st_ref.slices)
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (w, h, spp, flags, rows)
+    return st
+
+
+def test_two_calls_in_a_row_the_second_smaller():
+    s, m = O.random_world(1, -11, 11)
+    scene = hip.Scene(s, m)
+    cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, 16 / 9)
+    # sliced samples: the partial planes live in the fixed buffer
+    st = both(scene, cam, 256, 144, 32, 0)
+    assert st.slices > 1
+    st = both(scene, cam, 96, 54, 8, 0)                      # smaller, fewer slices
+    assert st.slices > 1
+    both(scene, cam, 256, 144, 32, 0, rows=(10, 50), resolve=False)   # a band, un-normalised sums
+    both(scene, cam, 64, 36, 5, abi.RT_FLAG_STRICT_FP)
+    # one slice: no planes, only the counters, so the frame may be of any size
+    st = both(scene, cam, 640, 360, 4, abi.RT_FLAG_SEQUENTIAL_SUM)
+    assert st.slices == 1
+    # the hierarchy was never built for this scene by an allocating call: refused, not built
+    frame = hip.make_frame(cam, 64, 36, 2, 50, 1, abi.RT_FLAG_ACCEL)
+    out = torch.zeros((36, 64, 3), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(hip.RtError) as e:
+        hip.render_rows_device_noalloc(scene, frame, 0, 36, True, out.data_ptr(), stream)
+    assert e.value.code == -1 and "hierarchy" in str(e.value)
+    both(scene, cam, 64, 36, 2, abi.RT_FLAG_ACCEL)           # the allocating call builds it first
+    scene.close()
+
+
+def test_a_request_beyond_the_fixed_buffer_is_refused():
+    s, m = O.random_world(1, -4, 4)
+    scene = hip.Scene(s, m)
+    cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, 16 / 9)
+    w, h, spp = 1920, 1080, 100                              # 50 slices x 24.9 MB
+    frame = hip.make_frame(cam, w, h, spp, 50, 1, 0)
+    out = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(hip.RtError) as e:
+        hip.render_rows_device_noalloc(scene, frame, 0, h, True, out.data_ptr(), stream)
+    assert e.value.code == -5 and "fixed buffer" in str(e.value)
+    assert float(out.abs().max()) == 0.0                     # nothing was launched
+    # the same frame a band at a time fits (50 slices x 1920 x 12 B per row: up to 58 rows)
+    band = torch.zeros((48, w, 3), dtype=torch.float32, device="cuda:0")
+    ref = torch.zeros_like(band)
+    hip.render_rows_device_noalloc(scene, frame, 512, 560, True, band.data_ptr(), stream)
+    hip.render_rows_device_async(scene, frame, 512, 560, True, ref.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(band.view(torch.int32), ref.view(torch.int32))
+    scene.close()
