@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz (MI355X)
 FLOP_PER_TEST = 17              # one ray/sphere discriminant, src/main.rs:131-135 with a hoisted
+FLOP_PER_TEST_EXECUTED = 16     # what the kernel's scan issues per test: 8 fused multiply-adds
 
 CONFIGS = {
     # the configuration the headline metric is quoted on
@@ -45,17 +46,45 @@ CONFIGS = {
 DEFAULT_CONFIG = "rtiow488_1080p_100spp_d50"
 
 
+def logical_cores():
+    """What num_cpus::get() (the reference's thread count, src/main.rs:923) reports on Linux:
+    the CPUs this process may run on, capped by a cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # cgroup v2: "<quota> <period>" or "max ..."
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:                                                # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, seed):
     """Time the oracle's dispatch_work_cpu_multithreaded on a bounded sample of the workload:
-    the same scene, camera, depth and per-pixel path distribution at 1/2 the resolution and
-    a bounded number of samples per pixel (cost is linear in pixels x spp)."""
+    the same scene, camera, depth, resolution and 64x64 tile queue (510 tiles at 1080p, so that
+    every thread has tiles to pop, as in the reference) at a bounded number of samples per pixel
+    (cost is linear in spp), on every logical core the process may use, like the reference's
+    `num_cpus::get()` (src/main.rs:923, src/cpu/multi.rs:131)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = min(16, os.cpu_count() or 1)
-    w, h, spp = cfg["width"] // 2, cfg["height"] // 2, 100
+    cores = logical_cores()
+    w, h = cfg["width"], cfg["height"]
     lo, hi = cfg["grid"]
-    if (hi - lo) ** 2 > 2000:
-        spp = 4
+    # about 10-30 s of CPU work in total: ~0.3 Msamples/s per core at 488 spheres
+    per_core_rate = 0.3e6 * 488.0 / ((hi - lo) ** 2 + 4)
+    spp = int(max(1, min(cfg["spp"], round(20.0 * per_core_rate * min(cores, 16) / (w * h)))))
     s, m = O.random_world(1, lo, hi, cfg.get("diffuse_below", 0.8), cfg.get("metal_below", 0.95),
                           1 if cfg.get("glass") else 0)
     cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, w / h)
@@ -65,10 +94,56 @@ def cpu_baseline(cfg, seed):
         "value": round(ctr.samples / secs * 1e-6, 4),
         "unit": "Msamples/s",
         "cores": cores,
+        "cores_source": "CPUs this process may run on, capped by its cgroup quota "
+                        "(num_cpus::get() semantics); os.cpu_count() = %d" % (os.cpu_count() or 0),
         "kind": "port",
-        "sample": "%dx%d @ %d spp, same scene/camera/max_depth (%d samples, %.1f s, %.3f rays/sample)"
-                  % (w, h, spp, ctr.samples, secs, ctr.rays / max(ctr.samples, 1)),
+        "sample": "%dx%d @ %d spp, same scene/camera/max_depth/tile queue (%d samples, %.1f s, "
+                  "%.3f rays/sample)" % (w, h, spp, ctr.samples, secs, ctr.rays / max(ctr.samples, 1)),
     }
+
+
+def drop_in_leg(hip, scene_host, camera, W, H, spp, depth, seed, steps, kernel_ms, n_devices):
+    """The call a host of the reference makes: rt_render with host pointers in and out (world
+    arrays in host memory, framebuffer in pageable host memory), wall time per call.  The first
+    call uploads the World and allocates; later calls on the same World reuse both, which is the
+    steady state timed here.  Where the process sees several GPUs, rt_render_multi over all of
+    them is timed the same way."""
+    import numpy as np
+    t0 = time.perf_counter()
+    fb = hip.render(scene_host.spheres, scene_host.materials, camera.m, W, H, spp, depth, seed)
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fb = hip.render(scene_host.spheres, scene_host.materials, camera.m, W, H, spp, depth, seed)
+    per_call = (time.perf_counter() - t0) / steps
+    out = {
+        "entry": "rt_render (host pointers in, pageable host framebuffer out)",
+        "ms_per_call": round(per_call * 1e3, 3),
+        "first_call_ms": round(first * 1e3, 3),
+        "overhead_vs_kernel_ms": round(per_call * 1e3 - kernel_ms, 3),
+        "value": round(W * H * spp / per_call * 1e-6, 2),
+        "unit": "Msamples/s",
+        "mean_rgb": [round(float(v), 5) for v in np.nanmean(fb, axis=(0, 1))],
+    }
+    if n_devices > 1:
+        devices = list(range(n_devices))
+        many = hip.render_multi(scene_host.spheres, scene_host.materials, camera.m, W, H, spp,
+                                depth, seed, devices)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            many = hip.render_multi(scene_host.spheres, scene_host.materials, camera.m, W, H, spp,
+                                    depth, seed, devices)
+        per_call = (time.perf_counter() - t0) / steps
+        same = np.array_equal(np.nan_to_num(many, nan=-1.0).view(np.uint32),
+                              np.nan_to_num(fb, nan=-1.0).view(np.uint32))
+        out["multi"] = {
+            "entry": "rt_render_multi (one process, %d GPUs)" % n_devices,
+            "ms_per_call": round(per_call * 1e3, 3),
+            "value": round(W * H * spp / per_call * 1e-6, 2),
+            "unit": "Msamples/s",
+            "same_pixels_as_rt_render": bool(same),
+        }
+    return out
 
 
 def profiled_traffic(config, kernel):
@@ -140,54 +215,60 @@ def main():
     scene = hip.Scene(scene_host.spheres, scene_host.materials)   # resident in HBM from here on
     frame = hip.make_frame(camera.m, W, H, spp, depth, args.seed, flags=0)
 
-    # Frames in flight: with one GPU a frame is 60 ms of work and frames run back to back on the
-    # current stream.  With the frame split over N GPUs a rank's share is short enough that the
-    # time its last deep paths take to drain shows, so consecutive frames go to alternating
-    # streams (each with its own output buffers) and the next frame's workgroups take over the
-    # compute units as the previous frame's retire.
-    n_flight = args.frames_in_flight or (1 if world == 1 else 2)
-    streams = ([torch.cuda.current_stream()] if n_flight == 1
-               else [torch.cuda.Stream(device=device) for _ in range(n_flight)])
+    # Frames in flight.  One frame at a time is the plain reading of "a step" and what `value`
+    # reports.  With the frame split over N GPUs a rank's share is short enough that the time
+    # its last deep paths take to drain shows; a host that renders a sequence of frames can put
+    # consecutive frames on alternating streams (each with its own output buffers) so that the
+    # next frame's workgroups take over the compute units as the previous frame's retire.  That
+    # is pipelined throughput, not a frame's latency, and is reported beside `value` as
+    # `pipelined` (N > 1 only, or when --frames-in-flight asks for it).
     plan = multi_gpu.RowPlan(W, H, world)
-    shardeds = [multi_gpu.ShardedFrame(plan, device, rank, stage_through_host=rehearsal)
-                for _ in range(n_flight)] if world > 1 else None
-    fulls = [torch.zeros((H, W, 3), dtype=torch.float32, device=device)
-             for _ in range(n_flight)] if world == 1 else None
-    step_no = [0]
 
-    def step():
-        i = step_no[0] % n_flight
-        step_no[0] += 1
-        with torch.cuda.stream(streams[i]):
-            raw = streams[i].cuda_stream
-            if world == 1:
-                hip.render_rows_device_async(scene, frame, 0, H, True, fulls[i].data_ptr(), raw)
-                return fulls[i]
+    def timed_run(n_flight):
+        streams = ([torch.cuda.current_stream()] if n_flight == 1
+                   else [torch.cuda.Stream(device=device) for _ in range(n_flight)])
+        shardeds = [multi_gpu.ShardedFrame(plan, device, rank, stage_through_host=rehearsal)
+                    for _ in range(n_flight)] if world > 1 else None
+        fulls = [torch.zeros((H, W, 3), dtype=torch.float32, device=device)
+                 for _ in range(n_flight)] if world == 1 else None
+        step_no = [0]
 
-            def render_fn(tiles, offs, strides, out):
-                hip.render_device_async(scene, frame, tiles, offs, strides, True, out.data_ptr(), raw)
+        def step():
+            i = step_no[0] % n_flight
+            step_no[0] += 1
+            with torch.cuda.stream(streams[i]):
+                raw = streams[i].cuda_stream
+                if world == 1:
+                    hip.render_rows_device_async(scene, frame, 0, H, True, fulls[i].data_ptr(), raw)
+                    return fulls[i]
 
-            return shardeds[i].render_and_gather(render_fn)
+                def render_fn(tiles, offs, strides, out):
+                    hip.render_device_async(scene, frame, tiles, offs, strides, True, out.data_ptr(), raw)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+                return shardeds[i].render_and_gather(render_fn)
+
+        def fence():
             torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fb = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fb = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, fb
 
+    n_flight = args.frames_in_flight or 1
+    elapsed, fb = timed_run(n_flight)
     launch_ms = hip.get_launch_ms(min(args.steps, 64))
     st = hip.get_stats()                       # this rank's last launch
     if n_flight == 1:
@@ -198,6 +279,17 @@ def main():
         # per-launch time is the timed region divided by its launches (includes reduce + gather)
         kernel_ms = elapsed / args.steps * 1e3
         kernel_ms_source = "timed region / launches (frames overlap, so event pairs do not isolate a launch)"
+    pipelined = None
+    if world > 1 and not args.frames_in_flight:
+        p_elapsed, _ = timed_run(2)
+        pipelined = {
+            "frames_in_flight": 2,
+            "value": round(W * H * spp * args.steps / p_elapsed * 1e-6, 2),
+            "unit": "Msamples/s",
+            "ms_per_step": round(p_elapsed / args.steps * 1e3, 3),
+            "note": "throughput with consecutive frames overlapped on two streams; ms_per_step "
+                    "here is the timed region divided by its frames, not one frame's latency",
+        }
     n_spheres = len(scene_host.spheres)
     flop = FLOP_PER_TEST * n_spheres * st.rays
     achieved = flop / (kernel_ms * 1e-3) * 1e-12 if kernel_ms > 0 else 0.0
@@ -226,7 +318,7 @@ def main():
                 "image": "%dx%d" % (W, H),
                 "samples_per_pixel": spp,
                 "max_depth": depth,
-                "frames_in_flight": n_flight,
+                "frames_in_flight": n_flight,   # of `value`; see `pipelined` for two
                 "sharding": "rows in blocks of %d dealt round-robin over %d rank(s)%s"
                             % (plan.block_rows, world, ", RCCL gather to rank 0" if world > 1 else ""),
             },
@@ -246,16 +338,25 @@ def main():
                 "rays_per_launch": int(st.rays),
                 "rays_per_sample": round(st.rays / max(st.samples, 1), 4),
                 "flop_per_ray_sphere_test": FLOP_PER_TEST,
+                "frac_executed": round(achieved / PEAK_FP32_VALU_TFLOPS
+                                       * FLOP_PER_TEST_EXECUTED / FLOP_PER_TEST, 4),
+                "frac_executed_note": "the same launch priced at the 16 flop (8 FMA) per test the "
+                                      "scan actually issues instead of the reference's 17",
                 "rank": 0,
             },
         }
+        if pipelined is not None:
+            line["pipelined"] = pipelined
+        if world == 1:
+            line["drop_in"] = drop_in_leg(hip, scene_host, camera, W, H, spp, depth, args.seed,
+                                          args.steps, kernel_ms, torch.cuda.device_count())
         if world == 1:
             # The opt-in mode that walks a bounding-volume hierarchy instead of testing every
             # sphere (RT_FLAG_ACCEL): same pixels, bit for bit, but not the brute-force work the
             # roofline above is counted in, so it is reported beside the headline, not as it.
             from ray_tracing_amd import abi
             aframe = hip.make_frame(camera.m, W, H, spp, depth, args.seed, flags=abi.RT_FLAG_ACCEL)
-            aout = torch.zeros_like(fulls[0])
+            aout = torch.zeros_like(fb)
             raw = torch.cuda.current_stream().cuda_stream
             hip.render_rows_device_async(scene, aframe, 0, H, True, aout.data_ptr(), raw)
             torch.cuda.synchronize()
