@@ -48,6 +48,7 @@ void ro_rng_counter(ro_rng* r, uint32_t seed, uint32_t pixel, uint32_t sample) {
   r->script = NULL;
   r->script_len = 0;
   r->draws = 0;
+  r->chacha = NULL;
 }
 
 void ro_rng_scripted(ro_rng* r, const float* values, uint32_t n) {
@@ -55,11 +56,22 @@ void ro_rng_scripted(ro_rng* r, const float* values, uint32_t n) {
   r->script = values;
   r->script_len = n;
   r->draws = 0;
+  r->chacha = NULL;
+}
+
+void ro_rng_chacha(ro_rng* r, ro_chacha* generator) {
+  r->counter = rt_rng_init(0, 0, 0);
+  r->script = NULL;
+  r->script_len = 0;
+  r->draws = 0;
+  r->chacha = generator;
 }
 
 float ro_random_f32(ro_rng* r) {
   float v;
-  if (r->script != NULL && r->draws < r->script_len) {
+  if (r->chacha != NULL) {
+    v = ro_chacha12_next_f32(r->chacha);
+  } else if (r->script != NULL && r->draws < r->script_len) {
     v = r->script[r->draws];
   } else {
     v = rt_rng_next_f32(&r->counter);
@@ -728,6 +740,77 @@ double ro_dispatch_multithreaded(const rt_tile* jobs, uint32_t n_jobs, const ro_
   if (!tile_sums) free(sums);
   free(off);
   return elapsed;
+}
+
+/* Moments of the estimator per pixel (see rt_oracle.h).  The sample loop is execute_job's
+ * (src/cpu/job.rs:48-59) with the reference's recursive shoot_ray. */
+typedef struct moments_shared {
+  pthread_mutex_t lock;
+  uint32_t next_row;
+  const ro_job_data* data;
+  int rng_kind;
+  double* sum;
+  double* sumsq;
+  ro_counters total;
+} moments_shared;
+
+static void* moments_worker(void* arg) {
+  moments_shared* sh = (moments_shared*)arg;
+  const ro_job_data* data = sh->data;
+  ro_counters local = {0, 0};
+  for (;;) {
+    pthread_mutex_lock(&sh->lock);
+    uint32_t y = sh->next_row;
+    if (y < data->image_height) sh->next_row = y + 1;
+    pthread_mutex_unlock(&sh->lock);
+    if (y >= data->image_height) break;
+    ro_chacha generator;
+    ro_chacha12_seed_from(&generator, data->seed, y, 0x726f7773u);
+    for (uint32_t x = 0; x < data->image_width; ++x) {
+      double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+      for (uint32_t sample = 0; sample < data->samples_per_pixel; ++sample) {
+        ro_rng rng;
+        if (sh->rng_kind == RO_RNG_CHACHA12) ro_rng_chacha(&rng, &generator);
+        else ro_rng_counter(&rng, data->seed, y * data->image_width + x, sample);
+        float u = ((float)x + ro_random_f32(&rng)) / (float)data->image_width;
+        float v = ((float)y + ro_random_f32(&rng)) / (float)data->image_height;
+        u = u * 2.0f - 1.0f;
+        v = v * 2.0f - 1.0f;
+        ro_ray ray = ro_camera_get_ray(data->camera, u, v);
+        ro_vec3 c = ro_shoot_ray(data->world, &ray, data->max_depth, &rng, &local);
+        local.samples++;
+        s1[0] += c.x; s1[1] += c.y; s1[2] += c.z;
+        s2[0] += (double)c.x * c.x; s2[1] += (double)c.y * c.y; s2[2] += (double)c.z * c.z;
+      }
+      size_t k = 3 * ((size_t)y * data->image_width + x);
+      for (int i = 0; i < 3; ++i) { sh->sum[k + i] = s1[i]; sh->sumsq[k + i] = s2[i]; }
+    }
+  }
+  pthread_mutex_lock(&sh->lock);
+  sh->total.rays += local.rays;
+  sh->total.samples += local.samples;
+  pthread_mutex_unlock(&sh->lock);
+  return NULL;
+}
+
+void ro_render_moments(const ro_job_data* data, int rng_kind, uint32_t num_threads, double* sum,
+                       double* sumsq, ro_counters* ctr) {
+  if (num_threads == 0) num_threads = 1;
+  moments_shared sh;
+  pthread_mutex_init(&sh.lock, NULL);
+  sh.next_row = 0;
+  sh.data = data;
+  sh.rng_kind = rng_kind;
+  sh.sum = sum;
+  sh.sumsq = sumsq;
+  sh.total.rays = 0;
+  sh.total.samples = 0;
+  pthread_t* threads = (pthread_t*)malloc(sizeof(pthread_t) * num_threads);
+  for (uint32_t i = 0; i < num_threads; ++i) pthread_create(&threads[i], NULL, moments_worker, &sh);
+  for (uint32_t i = 0; i < num_threads; ++i) pthread_join(threads[i], NULL);
+  if (ctr) { ctr->rays += sh.total.rays; ctr->samples += sh.total.samples; }
+  pthread_mutex_destroy(&sh.lock);
+  free(threads);
 }
 
 /* ------------------------------------------------------------------------------------------

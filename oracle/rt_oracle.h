@@ -50,18 +50,37 @@ typedef struct ro_world {
   uint32_t n_spheres;
 } ro_world;
 
+/* ChaCha12 as rand 0.8.5's thread_rng runs it (ro_chacha.c): an independent stream. */
+typedef struct ro_chacha {
+  uint32_t key[8];
+  uint64_t counter; /* next block */
+  uint64_t stream;
+  uint32_t buffer[16];
+  uint32_t index;   /* next unread word of buffer; 16 = empty */
+} ro_chacha;
+void ro_chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, int rounds,
+                     uint32_t out[16]);
+void ro_chacha12_seed(ro_chacha* c, const uint32_t key[8], uint64_t stream);
+void ro_chacha12_seed_from(ro_chacha* c, uint32_t seed, uint32_t a, uint32_t b);
+uint32_t ro_chacha12_next_u32(ro_chacha* c);
+float ro_chacha12_next_f32(ro_chacha* c);
+
 /* Source of "rand::random::<f32>()" values.  Three kinds:
  *   counter  : the rt_rng.h stream (shared with the GPU)
- *   scripted : values read from an array, for known-answer tests; counts what it hands out */
+ *   scripted : values read from an array, for known-answer tests; counts what it hands out
+ *   chacha   : a ChaCha12 generator that outlives the ro_rng (one per worker, like the
+ *              reference's thread-local generator), independent of rt_rng.h */
 typedef struct ro_rng {
   rt_rng counter;
   const float* script;
   uint32_t script_len;
   uint32_t draws; /* number of values handed out so far */
+  ro_chacha* chacha;
 } ro_rng;
 
 void ro_rng_counter(ro_rng* r, uint32_t seed, uint32_t pixel, uint32_t sample);
 void ro_rng_scripted(ro_rng* r, const float* values, uint32_t n);
+void ro_rng_chacha(ro_rng* r, ro_chacha* generator);
 float ro_random_f32(ro_rng* r);
 
 /* Per-call counters (thread-local accumulation is the caller's business). */
@@ -151,6 +170,19 @@ double ro_dispatch_singlethreaded(const rt_tile* jobs, uint32_t n_jobs, const ro
 double ro_dispatch_multithreaded(const rt_tile* jobs, uint32_t n_jobs, const ro_job_data* data,
                                  uint32_t num_threads, float* out_rgb, float* tile_sums,
                                  ro_counters* ctr);
+
+/* Per-pixel first and second moments of the estimator, for statistical comparisons: the
+ * reference's recursive shoot_ray (powf) over `samples_per_pixel` samples per pixel of the
+ * whole image, drawing either from the counter stream (rng_kind 0; data->seed, pixel, sample)
+ * or from ChaCha12 generators (rng_kind 1; one generator per image row keyed by data->seed and
+ * the row, consumed sample after sample and pixel after pixel like a worker thread's
+ * generator in the reference).  sum and sumsq receive W*H*3 doubles: the sum of the samples'
+ * radiance and of its square.  Rows are spread over num_threads threads; the result does not
+ * depend on the thread count. */
+#define RO_RNG_COUNTER 0
+#define RO_RNG_CHACHA12 1
+void ro_render_moments(const ro_job_data* data, int rng_kind, uint32_t num_threads, double* sum,
+                       double* sumsq, ro_counters* ctr);
 
 /* write_framebuffer_to_image: 24-bit BMP, y flipped, (c*255.0) as u8.  Returns 0 on success. */
 int ro_write_framebuffer_to_image(const char* path, uint32_t image_width, uint32_t image_height,

@@ -44,9 +44,14 @@ class RtRng(C.Structure):
     _fields_ = [("state", C.c_uint32), ("inc", C.c_uint32)]
 
 
+class Chacha(C.Structure):
+    _fields_ = [("key", C.c_uint32 * 8), ("counter", C.c_uint64), ("stream", C.c_uint64),
+                ("buffer", C.c_uint32 * 16), ("index", C.c_uint32)]
+
+
 class Rng(C.Structure):
     _fields_ = [("counter", RtRng), ("script", C.POINTER(C.c_float)), ("script_len", C.c_uint32),
-                ("draws", C.c_uint32)]
+                ("draws", C.c_uint32), ("chacha", C.POINTER(Chacha))]
 
 
 class Counters(C.Structure):
@@ -65,7 +70,7 @@ _lib = None
 
 def build():
     """Compile the oracle if the .so is missing or older than its sources."""
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("rt_oracle.c", "rt_oracle.h", "Makefile")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("rt_oracle.c", "ro_chacha.c", "rt_oracle.h", "Makefile")]
     srcs += [os.path.join(ROOT, "include", f) for f in ("rt_abi.h", "rt_rng.h")]
     if (not os.path.exists(ORACLE_SO)
             or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs)):
@@ -84,6 +89,16 @@ def lib():
     vp = C.c_void_p
     L.ro_rng_counter.argtypes = [C.POINTER(Rng), u32, u32, u32]
     L.ro_rng_scripted.argtypes = [C.POINTER(Rng), C.POINTER(f), u32]
+    L.ro_chacha_block.argtypes = [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_int,
+                                  C.POINTER(C.c_uint32)]
+    L.ro_chacha12_seed.argtypes = [C.POINTER(Chacha), C.POINTER(C.c_uint32), C.c_uint64]
+    L.ro_chacha12_seed_from.argtypes = [C.POINTER(Chacha), u32, u32, u32]
+    L.ro_chacha12_next_u32.argtypes = [C.POINTER(Chacha)]
+    L.ro_chacha12_next_u32.restype = u32
+    L.ro_chacha12_next_f32.argtypes = [C.POINTER(Chacha)]
+    L.ro_chacha12_next_f32.restype = f
+    L.ro_rng_chacha.argtypes = [C.POINTER(Rng), C.POINTER(Chacha)]
+    L.ro_render_moments.argtypes = [C.POINTER(JobData), C.c_int, u32, vp, vp, C.POINTER(Counters)]
     L.ro_random_f32.argtypes = [C.POINTER(Rng)]
     L.ro_random_f32.restype = f
     L.ro_mat4_look_at_rh.argtypes = [Vec3, Vec3, Vec3, C.POINTER(f)]
@@ -281,3 +296,23 @@ def render(spheres, materials, camera, width, height, spp, max_depth, seed,
     if want_sums:
         return fb, secs, ctr, sums
     return fb, secs, ctr
+
+
+RO_RNG_COUNTER = 0
+RO_RNG_CHACHA12 = 1
+
+
+def render_moments(spheres, materials, camera, width, height, spp, max_depth, seed, rng_kind,
+                   threads=8):
+    """ro_render_moments: per-pixel sum and sum of squares (float64, shape (H, W, 3)) of the
+    reference's recursive estimator over `spp` samples, drawn from the counter stream or from
+    independent ChaCha12 generators.  Returns (sum, sumsq, Counters)."""
+    world = make_world(spheres, materials)
+    data = JobData(width, height, max_depth, spp, seed, RO_MODE_RECURSIVE, C.pointer(camera),
+                   C.pointer(world))
+    s1 = np.zeros((height, width, 3), dtype=np.float64)
+    s2 = np.zeros((height, width, 3), dtype=np.float64)
+    ctr = Counters(0, 0)
+    lib().ro_render_moments(C.byref(data), int(rng_kind), int(threads), abi.ptr(s1), abi.ptr(s2),
+                            C.byref(ctr))
+    return s1, s2, ctr
