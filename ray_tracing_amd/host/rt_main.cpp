@@ -1,7 +1,9 @@
 // rt_main.cpp - the reference's main() (src/main.rs:841-941) with its CPU-renderer half kept
 // and the renderer swapped for the GPU: same hard-coded camera, create_random_world(), 64x64
 // job queue, debug_tiles.bmp, then `gpu.bmp` where the reference wrote singlethreaded.bmp /
-// multithreaded.bmp.  The wgpu experiment that precedes `return;` at src/main.rs:885 is not
+// multithreaded.bmp (src/main.rs:905-937; this library has no CPU renderer, so those two files
+// are not written here: tests/reference_driver.py writes them from the CPU oracle for
+// comparison).  The wgpu experiment that precedes `return;` at src/main.rs:885 is not
 // reproduced.
 //
 // usage: rt_main [width=1920] [spp=100] [max_depth=4] [grid=4] [seed=1] [outdir=.] [flags=0] [gpus=1]
@@ -50,7 +52,9 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     const auto framebuffer = cpu::dispatch_work_gpu(dispatch, seed, flags, num_gpus);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("Finished Jobs: 100.00\n");
+    // The reference's "Finished Jobs: xx.xx" line (src/cpu/multi.rs:111-114) polls the result
+    // vector every 500 ms; the GPU delivers the whole frame in one launch, so there is no
+    // intermediate state to report and no such line is printed.
     std::printf("Time: %.2f s (%lld ms)\n", secs, (long long)(secs * 1000.0));   // src/cpu/multi.rs:164-165
     std::printf("%.1f Msamples/s\n", (double)image_width * image_height * samples_per_pixel / secs * 1e-6);
     write_framebuffer_to_image(outdir + "/gpu.bmp", image_width, image_height, framebuffer);
