@@ -927,6 +927,10 @@ int rt_get_phase_cycles(uint64_t* out16) {
     RT_HIP(hipMemcpy(&c, sl.counters, sizeof c, hipMemcpyDeviceToHost));
   }
   for (int i = 0; i < 16; ++i) out16[i] = c.phase[i];
+#ifdef RT_DIAG_TRIGGERS
+  // developer build: slots 8-10 carry the scan's branch statistics instead of drain steps
+  for (int i = 0; i < 3; ++i) out16[8 + i] = c.phase[16 + i];
+#endif
   return RT_OK;
 }
 

@@ -75,6 +75,8 @@ struct PhaseClock {
   unsigned long long t_start, t_exhausted, tail_steps;
   unsigned long long drain_scan_steps, tail_cycles;
   unsigned long long cand, replay_iters;   // queued candidates (per lane), replay loop trips (per wave)
+  unsigned long long blocks, trig_blocks, trig_pairs;   // scan blocks, those that branched to the
+                                                        // queueing code, (sphere, path) pairs queued there
 };
 
 #ifndef RT_MIN_WAVES
@@ -376,7 +378,7 @@ __device__ __forceinline__ void prep_segment(Path& P) {
 template <bool STRICT, int NB>
 __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&r2)[NB],
                                            uint32_t first_index, Path (&P)[R], uint16_t* q,
-                                           uint32_t lane, bool& flush) {
+                                           uint32_t lane, bool& flush, PhaseClock& clk) {
   float disc[NB][R];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
@@ -417,13 +419,22 @@ __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&
       for (int r = 0; r < R; ++r) m = max(m, __float_as_int(disc[u][r]));
     any = m >= 0;
   }
+#ifdef RT_DIAG_PHASES
+  clk.blocks++;
+#endif
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
+#ifdef RT_DIAG_PHASES
+    clk.trig_blocks++;
+#endif
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const bool trig = !(disc[u][r] < 0.0f);   // `if discriminant < 0.0 { return false }`
         if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+#ifdef RT_DIAG_PHASES
+          clk.trig_pairs++;
+#endif
           if (trig && P[r].alive) {
             q[(r * Q + P[r].cnt) * kWave + lane] = (uint16_t)(first_index + u);
             P[r].cnt++;
@@ -506,24 +517,24 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
         rB[u] = STRICT ? sr2[i + U + u] : 0.0f;
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the read-ahead ahead of the arithmetic
-      test_block<STRICT, U>(A, rA, i, P, q, lane, flush);
+      test_block<STRICT, U>(A, rA, i, P, q, lane, flush, clk);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         A[u] = sph[i + 2 * U + u];
         rA[u] = STRICT ? sr2[i + 2 * U + u] : 0.0f;
       }
       __builtin_amdgcn_sched_barrier(0);
-      test_block<STRICT, U>(B, rB, i + U, P, q, lane, flush);
+      test_block<STRICT, U>(B, rB, i + U, P, q, lane, flush, clk);
     }
     if (!flush && i + U <= cn) {
-      test_block<STRICT, U>(A, rA, i, P, q, lane, flush);
+      test_block<STRICT, U>(A, rA, i, P, q, lane, flush, clk);
       i += U;
     }
     if (!flush) {
       for (; i < cn; ++i) {
         const float4 s1[1] = {sph[i]};
         const float r1[1] = {STRICT ? sr2[i] : 0.0f};
-        test_block<STRICT, 1>(s1, r1, i, P, q, lane, flush);
+        test_block<STRICT, 1>(s1, r1, i, P, q, lane, flush, clk);
       }
     }
     RT_STAMP(clk.scan, clk.t0);
@@ -1066,6 +1077,15 @@ void trace_kernel(const TraceParams p) {
     atomicAdd(&p.counters->phase[12], clk.tail_cycles);          // cycles inside tail_hit
     atomicAdd(&p.counters->phase[13], 1ull);                     // waves
   }
+#ifdef RT_DIAG_TRIGGERS
+  // a build for reading the scan's branch rate: {scan blocks, blocks that branched to the
+  // queueing code, (sphere, path) pairs queued there}, summed over waves
+  if (lane == 0) {
+    atomicAdd(&p.counters->phase[16], clk.blocks);
+    atomicAdd(&p.counters->phase[17], clk.trig_blocks);
+    atomicAdd(&p.counters->phase[18], clk.trig_pairs);
+  }
+#endif
   {
     // the hierarchy's counts, or (scan) queued candidates and 64 x the replay loop's trips
     const unsigned long long bi = ACCEL ? wave_sum(bvh_interior) : wave_sum((uint32_t)clk.cand);
