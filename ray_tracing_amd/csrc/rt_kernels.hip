@@ -544,42 +544,96 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
   }
 }
 
-// World::hit for the last few paths of a wave, one path at a time with the SPHERES spread over
-// the 64 lanes: lane l runs the exact test on spheres l, l+64, ... (read straight from global
-// memory, coalesced), then the wave takes the minimum t, the larger index winning a tie like a
-// later sphere does in World::hit's loop.  A step costs n/64 exact tests per lane instead of n
-// discriminants for all 128 paths, so the deep paths that are still alive when a frame drains
-// (max_depth 50 inside glass) finish an order of magnitude sooner.
-__device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, uint32_t lane) {
+// World::hit for the last paths of a wave.  When a wave has no work left and at most kTailPaths
+// live paths, scanning all 128 path slots against every sphere wastes most of its lanes, and
+// what remains is a chain of dependent steps (a path at max_depth 50 inside glass) that holds
+// the launch open.  Here the live paths are packed and the SPHERES are spread over lanes instead:
+// with n live paths, the wave is cut into groups of g = 64 / pow2(n) lanes, one group per path;
+// lane j of a group takes spheres j, j+g, ... first through the scan's conservative
+// discriminant (8 fused instructions; the literal arithmetic when STRICT) and, for the few that
+// pass, through the exact test; the group then takes the minimum t, the larger index winning a tie
+// like a later sphere does in World::hit's loop.  A step costs n_spheres / g cheap tests per lane.
+// The paths' rays travel to their groups, and the results back, through `xch`, the wave's own
+// candidate-queue memory (idle while nothing is scanned).
+// IN_LDS: the whole scene is resident in the workgroup's LDS (records in `sph`, radius^2 in
+// `sr2`); a chunked scene is read from global memory.
+constexpr int kTailFloats = 12;   // ox oy oz dx dy dz a ndx ndy ndz od noo
+static_assert((kTailFloats + 2) * kWave * sizeof(float) <= (size_t)R * Q * kWave * sizeof(uint16_t),
+              "the tail exchange must fit the wave's candidate queues");
+static_assert(kTailPaths <= (uint32_t)kWave, "one group of lanes per live path");
+
+template <bool STRICT, bool IN_LDS>
+__device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, const float4* sph,
+                                         const float* sr2, float* xch, uint32_t lane) {
+  // pack the live paths: slot numbers 0..n-1, path slot 0 of every lane first
+  uint32_t slot[R];
+  uint32_t n = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    unsigned long long m = __builtin_amdgcn_ballot_w64(P[r].alive);
-    while (m != 0) {
-      const int src = __builtin_ctzll(m);
-      m &= m - 1;
-      const float ox = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].ox), src));
-      const float oy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].oy), src));
-      const float oz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].oz), src));
-      const float dx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].dx), src));
-      const float dy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].dy), src));
-      const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].dz), src));
-      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(P[r].a), src));
-      float c = kTMax;
-      uint32_t b = kNone;
-      ReplayBounds rb = replay_bounds(c, a);
-      for (uint32_t i = lane; i < sc.n_spheres; i += kWave)
-        candidate_hit(sc.geom[i], i, mk(ox, oy, oz), mk(dx, dy, dz), a, rb, c, b);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(P[r].alive);
+    slot[r] = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    n += __builtin_popcountll(m);
+    if (P[r].alive) {
+      float* f = xch + slot[r];
+      f[0 * kWave] = P[r].ox; f[1 * kWave] = P[r].oy; f[2 * kWave] = P[r].oz;
+      f[3 * kWave] = P[r].dx; f[4 * kWave] = P[r].dy; f[5 * kWave] = P[r].dz;
+      f[6 * kWave] = P[r].a;
+      f[7 * kWave] = P[r].ndx; f[8 * kWave] = P[r].ndy; f[9 * kWave] = P[r].ndz;
+      f[10 * kWave] = P[r].od; f[11 * kWave] = P[r].noo;
+    }
+  }
+  if (n == 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // g lanes per path, a power of two: 64 for one path ... 1 for 33 to 64 paths
+  uint32_t shift = 0;                       // log2(g)
+  while (shift < 6 && (n << (shift + 1)) <= (uint32_t)kWave) ++shift;
+  const uint32_t g = 1u << shift;
+  const uint32_t path = lane >> shift, sub = lane & (g - 1);
+  float c = kTMax;
+  uint32_t b = kNone;
+  if (path < n) {
+    const float* f = xch + path;
+    const float ox = f[0 * kWave], oy = f[1 * kWave], oz = f[2 * kWave];
+    const float dx = f[3 * kWave], dy = f[4 * kWave], dz = f[5 * kWave];
+    const float a = f[6 * kWave];
+    const float ndx = f[7 * kWave], ndy = f[8 * kWave], ndz = f[9 * kWave];
+    const float od = f[10 * kWave], noo = f[11 * kWave];
+    ReplayBounds rb = replay_bounds(c, a);
+    for (uint32_t i = sub; i < sc.n_spheres; i += g) {
+      const float4 s = IN_LDS ? sph[i] : sc.trig[i];
+      if (!STRICT) {
+        // the same filter, with the same guarantee, as test_block's conservative form
+        const float hb = __builtin_fmaf(s.z, ndz, __builtin_fmaf(s.y, ndy, __builtin_fmaf(s.x, ndx, od)));
+        const float qh = __builtin_fmaf(s.z, oz, __builtin_fmaf(s.y, oy, __builtin_fmaf(s.x, ox, s.w)));
+        const float disc = __builtin_fmaf(hb, hb, __builtin_fmaf(qh, 2.0f, noo));
+        if (disc < 0.0f) continue;
+      }
+      const float4 geo = IN_LDS ? make_float4(s.x, s.y, s.z, sr2[i]) : sc.geom[i];
+      candidate_hit(geo, i, mk(ox, oy, oz), mk(dx, dy, dz), a, rb, c, b);
+    }
+  }
+  // minimum over the lanes of each group (all 64 lanes take part; idle ones carry "no hit")
+  for (uint32_t off = g >> 1; off > 0; off >>= 1) {
+    const float oc = __shfl_xor(c, (int)off, kWave);
+    const uint32_t ob = (uint32_t)__shfl_xor((int)b, (int)off, kWave);
+    const bool take = ob != kNone && (b == kNone || oc < c || (oc == c && ob > b));
+    if (take) { c = oc; b = ob; }
+  }
+  float* res = xch + kTailFloats * kWave;
+  if (path < n && sub == 0) {
+    res[path] = c;
+    res[kWave + path] = __uint_as_float(b);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const float oc = __shfl_xor(c, off, kWave);
-        const uint32_t ob = (uint32_t)__shfl_xor((int)b, off, kWave);
-        const bool take = ob != kNone && (b == kNone || oc < c || (oc == c && ob > b));
-        if (take) { c = oc; b = ob; }
-      }
-      if (lane == (uint32_t)src) {
-        P[r].closest = c;
-        P[r].best = b;
-      }
+  for (int r = 0; r < R; ++r) {
+    if (P[r].alive) {
+      P[r].closest = res[slot[r]];
+      P[r].best = __float_as_uint(res[kWave + slot[r]]);
     }
   }
 }
@@ -1010,9 +1064,9 @@ void trace_kernel(const TraceParams p) {
         __syncthreads();
         if (!tail) scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
       }
-      if (tail) tail_hit(P, p.scene, lane);
+      if (tail) tail_hit<STRICT, false>(P, p.scene, sph, sr2, reinterpret_cast<float*>(q), lane);
     } else {
-      if (tail) tail_hit(P, p.scene, lane);
+      if (tail) tail_hit<STRICT, true>(P, p.scene, sph, sr2, reinterpret_cast<float*>(q), lane);
       else scan_chunk<STRICT>(P, sph, sr2, n, 0, q, lane, clk);
     }
 #ifdef RT_DIAG_PHASES

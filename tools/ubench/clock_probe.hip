@@ -257,6 +257,61 @@ __global__ void k_scan(Stamp* st, const float4* __restrict__ spheres, int n, int
   out[tid] = (float)cnt;
 }
 
+// The production scan with the sphere records read through the scalar cache into SGPRs, four
+// records (64 bytes) per s_load_dwordx16, requested one block ahead by hand: the load of block
+// k+1 is issued before block k is evaluated and waited for only when block k+1 begins, so its
+// latency hides behind a whole block of arithmetic (the compiler, left to itself, waits right
+// after issuing).  Every fma then reads two VGPRs and one SGPR instead of three VGPRs.
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int R>
+__global__ void k_scan_smem(Stamp* st, const float4* __restrict__ spheres, int n, int reps, float* out) {
+  float ox[R], oy[R], oz[R], nx[R], ny[R], nz[R], od[R], hnoo[R];
+  unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    unsigned h = (tid * R + r) * 2654435761u;
+    ox[r] = 13.f + (h & 255) * 1e-3f; oy[r] = 2.f + ((h >> 8) & 255) * 1e-3f; oz[r] = 3.f + (h & 7) * 1e-3f;
+    nx[r] = 0.96f - ((h >> 16) & 255) * 1e-3f; ny[r] = 0.15f + (h & 3) * 1e-3f; nz[r] = 0.22f - (h >> 24) * 1e-3f;
+    od[r] = -(ox[r] * nx[r] + oy[r] * ny[r] + oz[r] * nz[r]);
+    hnoo[r] = -0.5f * (ox[r] * ox[r] + oy[r] * oy[r] + oz[r] * oz[r]);
+  }
+  int cnt = 0;
+  auto block = [&](const f16v& s) {
+    int m = (int)0x80000000;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float hb = __builtin_fmaf(s[4 * u + 2], nz[r], __builtin_fmaf(s[4 * u + 1], ny[r], __builtin_fmaf(s[4 * u], nx[r], od[r])));
+        float t = __builtin_fmaf(s[4 * u + 2], oz[r], __builtin_fmaf(s[4 * u + 1], oy[r], __builtin_fmaf(s[4 * u], ox[r], hnoo[r])));
+        float disc = __builtin_fmaf(hb, hb, __builtin_fmaf(t, 2.0f, s[4 * u + 3]));
+        m = max(m, __float_as_int(disc));
+      }
+    }
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(m >= 0) != 0, 0)) cnt += (m >= 0);
+  };
+  unsigned long long c0, t0;
+  stamp_begin(c0, t0);
+  for (int rep = 0; rep < reps; ++rep) {
+    const float4* base = spheres;
+    f16v A, B;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(A) : "s"(base) : "memory");
+    for (int i = 0; i + 8 <= n; i += 8) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A) : : "memory");
+      asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(B) : "s"(base) : "memory");
+      block(A);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(B) : : "memory");
+      asm volatile("s_load_dwordx16 %0, %1, 0x80" : "=s"(A) : "s"(base) : "memory");
+      block(B);
+      base += 8;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A) : : "memory");
+    ox[0] += 1e-6f;
+  }
+  stamp_end(st, c0, t0);
+  out[tid] = (float)cnt;
+}
+
 static void report(const char* name, int wps, double instr_per_wave, const std::vector<Stamp>& st,
                    float ms, double flop_per_instr_lane) {
   double cyc = 0, ticks = 0, cmax = 0;
@@ -284,8 +339,8 @@ int main(int argc, char** argv) {
          prop.gcnArchName);
   const int cus = prop.multiProcessorCount;
   const int n = 488;
-  std::vector<float4> sph(n + 8);
-  for (int i = 0; i < n + 8; ++i) {
+  std::vector<float4> sph(n + 16);
+  for (int i = 0; i < n + 16; ++i) {
     const float x = (float)(i % 22) - 11.f + 0.3f, z = (float)(i / 22) - 11.f + 0.4f;
     const float k = x * x + 0.04f + z * z - 0.04f;
     sph[i] = make_float4(x, 0.2f, z, -0.5f * k);
@@ -366,6 +421,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(st.data(), d_st, waves * sizeof(Stamp), hipMemcpyDeviceToHost));
     // per wave: reps * (488 / 8) iterations * 2 blocks * (64 fma + 4 max3 + 1 cmp)
     report("scan R=2", wps, (double)reps * (n / 8) * 2 * 69, st, ms, 2.0 * 64.0 / 69.0);
+    for (int pass = 0; pass < 2; ++pass) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL((k_scan_smem<2>), dim3(blocks), dim3(threads), 0, 0, d_st, d_sph, n, reps, d_out);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+    }
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(st.data(), d_st, waves * sizeof(Stamp), hipMemcpyDeviceToHost));
+    report("scan smem", wps, (double)reps * (n / 8) * 2 * 69, st, ms, 2.0 * 64.0 / 69.0);
     CK(hipFree(d_st));
     CK(hipFree(d_out));
   }
