@@ -368,6 +368,8 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   uint32_t slice_begin[rt::kMaxSlices + 1];
   p.slices = plan_slices(*frame, slice_begin, &p.body_slices);
   for (uint32_t k = 0; k <= p.slices; ++k) p.slice_begin[k] = sample_begin + slice_begin[k];
+  p.body_div = rt::make_divider(p.body_slices);
+  p.tail_div = rt::make_divider(p.slices - p.body_slices);
   p.n_tiles = (uint32_t)n_tiles;
   uint64_t total_pixels = 0;
   for (size_t i = 0; i < n_tiles; ++i) total_pixels += (uint64_t)tiles[i].w * tiles[i].h;
@@ -762,7 +764,8 @@ int tile_table(const rt_frame* frame, const rt_tile* tiles, const uint64_t* out_
                   tiles[i].width);
     rt::TileDev t;
     memset(&t, 0, sizeof t);
-    t.x = tiles[i].x; t.y = tiles[i].y; t.w = tiles[i].width; t.h = tiles[i].height;
+    t.x = tiles[i].x; t.y = tiles[i].y; t.h = tiles[i].height;
+    rt::set_tile_width(t, tiles[i].width);
     t.first_pixel = (uint32_t)first;
     t.out_stride = out_stride[i];
     t.out_offset = out_offset[i];
@@ -775,14 +778,14 @@ int tile_table(const rt_frame* frame, const rt_tile* tiles, const uint64_t* out_
   return RT_OK;
 }
 
-rt::TileDev rows_tile(const rt_frame* frame, uint32_t row_begin, uint32_t row_end) {
-  rt::TileDev t;
+void rows_tile(const rt_frame* frame, uint32_t row_begin, uint32_t row_end, rt::TileDev* out) {
+  rt::TileDev& t = *out;
   memset(&t, 0, sizeof t);
-  t.x = 0; t.y = row_begin; t.w = frame->image_width; t.h = row_end - row_begin;
+  t.x = 0; t.y = row_begin; t.h = row_end - row_begin;
+  rt::set_tile_width(t, frame->image_width);
   t.first_pixel = 0;
   t.out_stride = frame->image_width;
   t.out_offset = 0;
-  return t;
 }
 
 int check_rows(const rt_scene* scene, const rt_frame* frame, uint32_t row_begin, uint32_t row_end) {
@@ -859,7 +862,8 @@ int rt_render_rows_device_async(const rt_scene* scene, const rt_frame* frame, ui
   if (row_begin == row_end) return RT_OK;
   if (!d_out) return fail(RT_ERR_INVALID_ARGUMENT, "d_out is NULL");
   if (int rc = check_device_pointer(d_out, "d_out")) return rc;
-  const rt::TileDev t = rows_tile(frame, row_begin, row_end);
+  rt::TileDev t;
+  rows_tile(frame, row_begin, row_end, &t);
   hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
   return render_tiles_device(scene, frame, &t, 1, (uint64_t)t.w * t.h, resolve, d_out, s);
 }
@@ -872,7 +876,8 @@ int rt_render_rows_device_noalloc(const rt_scene* scene, const rt_frame* frame, 
   if (row_begin == row_end) return RT_OK;
   if (!d_out) return fail(RT_ERR_INVALID_ARGUMENT, "d_out is NULL");
   if (!ctx().scratch) return fail(RT_ERR_NOT_INITIALIZED, "the fixed buffer has no address");
-  const rt::TileDev t = rows_tile(frame, row_begin, row_end);
+  rt::TileDev t;
+  rows_tile(frame, row_begin, row_end, &t);
   hipStream_t s = stream ? (hipStream_t)stream : ctx().stream;
   return render_tiles_device(scene, frame, &t, 1, (uint64_t)t.w * t.h, resolve, d_out, s, 0, false,
                              /*no_alloc=*/true);
@@ -1010,7 +1015,8 @@ struct Share {
   void add(uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint32_t image_width) {
     rt::TileDev t;
     memset(&t, 0, sizeof t);
-    t.x = x; t.y = y; t.w = w; t.h = h;
+    t.x = x; t.y = y; t.h = h;
+    rt::set_tile_width(t, w);
     t.first_pixel = (uint32_t)pixels;
     t.out_stride = w;
     t.out_offset = pixels;

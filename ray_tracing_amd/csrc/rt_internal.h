@@ -54,13 +54,47 @@ constexpr uint32_t kTailPaths = RT_TAIL_PATHS;  // a wave with no work left and 
                                                 // live paths traces them with the spheres spread
                                                 // across its lanes
 
+// Division of a 32-bit number by a divisor fixed on the host (Granlund and Montgomery's
+// round-up method): q = (t + ((n - t) >> sh1)) >> sh2 with t = mulhi(n, mul), exact for every
+// 32-bit n and every divisor from 1 to 2^32 - 1.  Five instructions where the general division
+// the compiler emits takes about thirty.
+struct Divider {
+  uint32_t mul = 1;
+  uint16_t sh1 = 0, sh2 = 0;
+};
+inline Divider make_divider(uint32_t d) {
+  Divider v;
+  if (d == 0) d = 1;
+  uint32_t l = 0;                                   // ceil(log2 d)
+  while (l < 32 && (1ull << l) < d) ++l;
+  v.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  v.sh1 = l < 1 ? (uint16_t)l : 1;
+  v.sh2 = l < 1 ? 0 : (uint16_t)(l - 1);
+  return v;
+}
+#if defined(__HIPCC__)
+__host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const Divider& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t t = __umulhi(n, v.mul);
+#else
+  const uint32_t t = (uint32_t)(((uint64_t)n * v.mul) >> 32);
+#endif
+  return (t + ((n - t) >> v.sh1)) >> v.sh2;
+}
+#endif
+
 // One tile of the request as the kernel sees it.
 struct TileDev {
   uint32_t x, y, w, h;
   uint32_t first_pixel;   // exclusive prefix sum of w*h over the tile list
   uint32_t out_stride;    // pixels between rows of this tile in the output
   uint64_t out_offset;    // pixel index of the tile's first pixel in the output
+  Divider wdiv;           // division by w (make_divider(w)); set_tile_width fills both
 };
+inline void set_tile_width(TileDev& t, uint32_t w) {
+  t.w = w;
+  t.wdiv = make_divider(w);
+}
 
 // Device copy of a World (reference src/main.rs:168-172), split hot/cold:
 //   trig[i] = (cx, cy, cz, -k'/2)               read by every ray for every sphere; k' is
@@ -126,6 +160,7 @@ struct TraceParams {
   uint32_t slices;          // work items (and partial-sum planes) per pixel
   uint32_t body_slices;     // the first body_slices slices are issued first, pixel-major;
                             // the remaining (short) ones after them, pixel-major again
+  Divider body_div, tail_div;   // division by body_slices and by slices - body_slices
   uint32_t slice_begin[kMaxSlices + 1];   // slice k runs samples [slice_begin[k], slice_begin[k+1])
   uint32_t n_tiles;
   uint32_t total_pixels;

@@ -155,9 +155,16 @@ __device__ __forceinline__ float reflectance(float cosine, float ref_index) {
   float x4 = x2 * x2;
   return r0 + (1.0f - r0) * (x4 * x);
 }
-// sky, src/main.rs:256-262
-__device__ __forceinline__ V3 sky(V3 dir) {
-  V3 u = normalize(dir);
+// 1 / |d| as glam's normalize forms it, from a = dot(d, d) of the segment (src/main.rs:132 and
+// the `v * (1.0 / sqrt(dot(v, v)))` of normalize share that dot product bit for bit).  The sky
+// and the dielectric branch both normalise the ray direction; computing the factor once ahead
+// of them takes the square root and the division out of both.
+__device__ __forceinline__ float inv_length(float a) {
+  return 1.0f / __builtin_sqrtf(a);
+}
+// sky, src/main.rs:256-262; inv_len = inv_length(dot(dir, dir))
+__device__ __forceinline__ V3 sky(V3 dir, float inv_len) {
+  V3 u = scale(dir, inv_len);
   float t = 0.5f * (u.y + 1.0f);
   float s = 1.0f - t;
   return mk(s * 1.0f + t * 0.5f, s * 1.0f + t * 0.7f, s * 1.0f + t * 1.0f);
@@ -249,7 +256,7 @@ struct Bounce {
   V3 atten;  // factor on the next segment's radiance
 };
 
-__device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, float t,
+__device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, float inv_len, float t,
                                             uint32_t sphere, PathRng& rng) {
   Bounce b;
   const float4 g = sc.geom[sphere];
@@ -276,7 +283,7 @@ __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, floa
     b.kind = RT_KIND_DIELECTRIC;
     float ir = m1.y;
     float ratio = b.front ? 1.0f / ir : ir;
-    V3 u = normalize(d);
+    V3 u = scale(d, inv_len);   // normalize(d)
     float cos_theta = __builtin_fminf(dot(neg(u), b.normal), 1.0f);
     float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
     bool cannot_refract = (ratio * sin_theta) > 1.0f;
@@ -849,18 +856,18 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TracePa
   if (p.slices != 1) {
     const uint32_t body_items = p.total_pixels * p.body_slices;
     if (item < body_items) {
-      g = item / p.body_slices;
+      g = fast_div(item, p.body_div);
       sl = item - g * p.body_slices;
     } else {
       const uint32_t tail_slices = p.slices - p.body_slices;
       const uint32_t j = item - body_items;
-      g = j / tail_slices;
+      g = fast_div(j, p.tail_div);
       sl = p.body_slices + (j - g * tail_slices);
     }
   }
   const TileDev t = find_tile(g, p.n_tiles, p.tile0, p.tiles);
   const uint32_t local = g - t.first_pixel;
-  const uint32_t ty = local / t.w;
+  const uint32_t ty = fast_div(local, t.wdiv);
   const uint32_t tx = local - ty * t.w;
   const uint32_t px = t.x + tx, py = t.y + ty;
   P.fx = (float)px;
@@ -1083,11 +1090,12 @@ void trace_kernel(const TraceParams p) {
         const V3 o = mk(P[r].ox, P[r].oy, P[r].oz), d = mk(P[r].dx, P[r].dy, P[r].dz);
         bool ended;
         V3 radiance = mk(0.0f, 0.0f, 0.0f);
+        const float inv_len = inv_length(P[r].a);
         if (P[r].best == kNone) {
-          radiance = mul(mk(P[r].tr, P[r].tg, P[r].tb), sky(d));
+          radiance = mul(mk(P[r].tr, P[r].tg, P[r].tb), sky(d, inv_len));
           ended = true;
         } else {
-          const Bounce b = shade_hit(p.scene, o, d, P[r].closest, P[r].best, P[r].rng);
+          const Bounce b = shade_hit(p.scene, o, d, inv_len, P[r].closest, P[r].best, P[r].rng);
           if (!b.scattered) {
             ended = true;
           } else {
@@ -1165,7 +1173,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
        g += gridDim.x * blockDim.x) {
     const TileDev t = find_tile(g, p.n_tiles, p.tile0, p.tiles);
     const uint32_t local = g - t.first_pixel;
-    const uint32_t ty = local / t.w;
+    const uint32_t ty = fast_div(local, t.wdiv);
     const uint32_t tx = local - ty * t.w;
     const uint64_t o = t.out_offset + (uint64_t)ty * t.out_stride + tx;
     float r = 0.0f, gch = 0.0f, b = 0.0f;   // slices == 0: the covered pixels are set to zero
@@ -1267,13 +1275,14 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   out.px = out.py = out.pz = 0.0f;
   out.nx = out.ny = out.nz = 0.0f;
   out.sx = out.sy = out.sz = 0.0f;
+  const float inv_len = inv_length(P[0].a);
   if (P[0].best == kNone) {
-    const V3 s = sky(d);
+    const V3 s = sky(d, inv_len);
     out.hit = 0;
     out.kind = RT_KIND_MISS;
     out.ar = s.x; out.ag = s.y; out.ab = s.z;
   } else {
-    const Bounce b = shade_hit(p.scene, o, d, P[0].closest, P[0].best, rng);
+    const Bounce b = shade_hit(p.scene, o, d, inv_len, P[0].closest, P[0].best, rng);
     out.hit = 1;
     out.sphere = P[0].best;
     out.material = b.material;

@@ -63,3 +63,17 @@ def test_degenerate_inputs(checker):
     pts = rs.uniform(-1e6, 1e6, size=(200, 3))
     rad = rs.choice([0.0, -0.3, 0.2, 5.0], size=(200, 1))
     run(checker, np.hstack([pts, rad]))
+
+
+def test_host_prepared_dividers_match_integer_division(tmp_path):
+    """The kernel divides work-item numbers by the slice count and the tile width with
+    multipliers prepared on the host (rt::make_divider / rt::fast_div); the same inline code,
+    compiled for the host, against `/` over edge cases and a sweep."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path / "divider_check")
+    subprocess.run([HIPCC, "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950",
+                    os.path.join(ROOT, "tests", "native", "divider_check.cpp"), "-o", out],
+                   check=True, capture_output=True, timeout=300)
+    p = subprocess.run([out], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.startswith("ok "), p.stdout + p.stderr
