@@ -165,7 +165,7 @@ struct TraceParams {
   uint32_t n_tiles;
   uint32_t total_pixels;
   uint32_t total_items;     // total_pixels * slices
-  uint64_t out_pixels;      // pixels in one slice of the output (slice stride)
+  uint64_t out_pixels;      // pixels the output spans (its last covered pixel + 1)
   TileDev tile0;            // the tile list when n_tiles == 1
   const TileDev* tiles;     // otherwise
   float* out;               // final buffer (slices == 1) or partial-sum buffer
@@ -179,7 +179,7 @@ struct TraceParams {
 };
 
 struct ReduceParams {
-  const float* partial;   // [slices][out_pixels][3]
+  const float* partial;   // [out_pixels][slices][3]
   float* out;             // [out_pixels][3]
   uint64_t out_pixels;
   uint32_t slices;

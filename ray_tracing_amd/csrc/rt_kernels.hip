@@ -48,6 +48,14 @@
 
 #include "../../include/rt_rng.h"
 
+// -DRT_ASM_MARKS (the `asm` target of the Makefile) leaves a comment in the ISA at every phase
+// boundary, so that instructions can be counted per phase (tools/phase_instructions.py).
+#ifdef RT_ASM_MARKS
+#define RT_MARK(name) asm volatile("; RTMARK " name)
+#else
+#define RT_MARK(name) do { } while (0)
+#endif
+
 #ifdef RT_DIAG_PHASES
 #define RT_STAMP(acc, t0)                                                   \
   do {                                                                      \
@@ -505,6 +513,7 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
   uint32_t i = 0;
   while (i < cn) {
     bool flush = false;
+    RT_MARK("scan");
     RT_PRIO_SCAN();
     // The records of the next block are read from LDS while the current one is evaluated,
     // so the read latency is off the critical path: two register sets, A and B, alternate
@@ -546,7 +555,9 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
     }
     RT_STAMP(clk.scan, clk.t0);
     RT_PRIO_REST();
+    RT_MARK("replay");
     replay_queue(P, sph, sr2, chunk_base, q, lane, clk);
+    RT_MARK("replay_end");
     RT_STAMP(clk.replay, clk.t0);
   }
 }
@@ -873,7 +884,12 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TracePa
   P.fx = (float)px;
   P.fy = (float)py;
   P.pixel = py * p.width + px;
-  P.out_index = (uint32_t)(t.out_offset + (uint64_t)ty * t.out_stride + tx + sl * p.out_pixels);
+  // Where the item's sum goes: the pixel's place in the output, or, with sliced samples, entry
+  // `sl` of the pixel's run of `slices` partial sums.  The items a wave reserves together are
+  // the slices of one or two pixels, so their stores fill whole cache lines of one L2.  All
+  // below 2^32 (checked on the host), so 32-bit arithmetic does.
+  const uint32_t at = (uint32_t)t.out_offset + ty * t.out_stride + tx;
+  P.out_index = p.slices != 1 ? at * p.slices + sl : at;
   P.sample = p.slice_begin[sl];
   P.sample_end = p.slice_begin[sl + 1];
   P.ar = P.ag = P.ab = 0.0f;
@@ -1008,6 +1024,7 @@ void trace_kernel(const TraceParams p) {
 #endif
 
   for (;;) {
+    RT_MARK("refill");
     // ---- refill: next sample of the item, or the next item ------------------------------
 #pragma unroll
     for (int r = 0; r < RP; ++r) {
@@ -1034,6 +1051,7 @@ void trace_kernel(const TraceParams p) {
     }
 
     RT_STAMP(clk.refill, clk.t0);
+    RT_MARK("hit_setup");
     clk.steps++;
 
     // ---- World::hit --------------------------------------------------------------------
@@ -1083,6 +1101,7 @@ void trace_kernel(const TraceParams p) {
 #endif
 
     // ---- the rest of shoot_ray's body ----------------------------------------------------
+    RT_MARK("shade");
 #pragma unroll
     for (int r = 0; r < RP; ++r) {
       if (P[r].alive) {
@@ -1118,7 +1137,9 @@ void trace_kernel(const TraceParams p) {
       }
     }
     RT_STAMP(clk.shade, clk.t0);
+    RT_MARK("shade_end");
   }
+  RT_MARK("epilogue");
 
 #ifdef RT_DIAG_PHASES
   if (lane == 0) {
@@ -1166,35 +1187,59 @@ void trace_kernel(const TraceParams p) {
   }
 }
 
-// Sum the planes of each covered pixel in slice order and optionally resolve
-// (compose_final_framebuffer's arithmetic, src/cpu/mod.rs:67-75).
+// Sum the partial sums of each covered pixel in slice order and optionally resolve
+// (compose_final_framebuffer's arithmetic, src/cpu/mod.rs:67-75).  HBM-bound.  A pixel's partial
+// sums are one contiguous run of slices * 3 floats; a workgroup takes kReducePixels pixels at a
+// time, its four waves copy their pixels' runs into LDS with coalesced loads, and one thread per
+// (pixel, channel) then adds that channel's values in slice order.
+constexpr uint32_t kReducePixels = 64;
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
-  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < p.total_pixels;
-       g += gridDim.x * blockDim.x) {
-    const TileDev t = find_tile(g, p.n_tiles, p.tile0, p.tiles);
-    const uint32_t local = g - t.first_pixel;
-    const uint32_t ty = fast_div(local, t.wdiv);
-    const uint32_t tx = local - ty * t.w;
-    const uint64_t o = t.out_offset + (uint64_t)ty * t.out_stride + tx;
-    float r = 0.0f, gch = 0.0f, b = 0.0f;   // slices == 0: the covered pixels are set to zero
-    if (p.slices != 0) {
-      const float* src = p.partial + 3ull * o;
-      r = src[0]; gch = src[1]; b = src[2];
-      for (uint32_t k = 1; k < p.slices; ++k) {
-        const float* pl = src + 3ull * k * p.out_pixels;
-        r += pl[0]; gch += pl[1]; b += pl[2];
+  extern __shared__ __align__(16) float red[];             // [kReducePixels][slices * 3]
+  __shared__ unsigned long long where[kReducePixels];      // output pixel index of each slot
+  const uint32_t run = p.slices * 3;
+  const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  for (uint32_t first = blockIdx.x * kReducePixels; first < p.total_pixels;
+       first += gridDim.x * kReducePixels) {
+    if (threadIdx.x < kReducePixels && first + threadIdx.x < p.total_pixels) {
+      const uint32_t g = first + threadIdx.x;
+      const TileDev t = find_tile(g, p.n_tiles, p.tile0, p.tiles);
+      const uint32_t local = g - t.first_pixel;
+      const uint32_t ty = fast_div(local, t.wdiv);
+      const uint32_t tx = local - ty * t.w;
+      where[threadIdx.x] = t.out_offset + (unsigned long long)ty * t.out_stride + tx;
+    }
+    __syncthreads();
+    const uint32_t count = p.total_pixels - first < kReducePixels ? p.total_pixels - first : kReducePixels;
+    // Pixels that follow each other in the output (the rule inside a tile row) form one
+    // contiguous block of count * run floats: copied 16 bytes per thread when it is so aligned.
+    const float* block = p.partial + where[0] * run;
+    const bool contiguous = where[count - 1] - where[0] == count - 1 &&
+                            (reinterpret_cast<uintptr_t>(block) & 15u) == 0 && ((count * run) & 3u) == 0;
+    if (contiguous) {
+      const float4* src4 = reinterpret_cast<const float4*>(block);
+      float4* red4 = reinterpret_cast<float4*>(red);
+      for (uint32_t i = threadIdx.x; i < count * run / 4; i += 256) red4[i] = src4[i];
+    } else {
+      for (uint32_t k = wave; k < count; k += 256 / kWave) {
+        const float* src = p.partial + where[k] * run;
+        for (uint32_t i = lane; i < run; i += kWave) red[k * run + i] = src[i];
       }
     }
-    float* dst = p.out + 3ull * o;
-    if (p.accumulate) {
-      r = dst[0] + r; gch = dst[1] + gch; b = dst[2] + b;
+    __syncthreads();
+    if (threadIdx.x < count * 3) {
+      const uint32_t k = threadIdx.x / 3, ch = threadIdx.x - 3 * k;
+      float v = 0.0f;                       // slices == 0: the covered pixels are set to zero
+      if (p.slices != 0) {
+        const float* mine = red + k * run + ch;
+        v = mine[0];
+        for (uint32_t sl = 1; sl < p.slices; ++sl) v += mine[3 * sl];
+      }
+      float* dst = p.out + 3ull * where[k] + ch;
+      if (p.accumulate) v = *dst + v;
+      if (p.resolve) v = resolve_channel(v, p.inv_spp);
+      *dst = v;
     }
-    if (p.resolve) {
-      r = resolve_channel(r, p.inv_spp);
-      gch = resolve_channel(gch, p.inv_spp);
-      b = resolve_channel(b, p.inv_spp);
-    }
-    dst[0] = r; dst[1] = gch; dst[2] = b;
+    __syncthreads();
   }
 }
 
@@ -1357,10 +1402,11 @@ hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, int block
 }
 
 hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream) {
-  uint64_t blocks = ((uint64_t)p.total_pixels + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  uint64_t blocks = ((uint64_t)p.total_pixels + kReducePixels - 1) / kReducePixels;
+  if (blocks > 16384) blocks = 16384;
   if (blocks == 0) return hipSuccess;
-  hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  const size_t lds = (size_t)kReducePixels * (p.slices ? p.slices : 1) * 3 * sizeof(float);
+  hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, p);
   return hipGetLastError();
 }
 
