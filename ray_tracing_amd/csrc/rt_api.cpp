@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt_rng.h"
@@ -73,7 +74,6 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int kEventRing = 64;
 constexpr int kLaunchSlots = 4;
-constexpr int kCopyChunks = 8;   // pieces a frame goes back to the host in (rt_render)
 
 // What one in-flight render owns on the device.  Launches on the same stream run one after the
 // other and share a slot; launches on different streams may overlap on the GPU, so each stream
@@ -91,7 +91,8 @@ struct LaunchSlot {
 };
 
 // What the host-pointer entry points keep between calls on one device: the device copy of the
-// last World they were given, the frame in device memory and a pinned staging buffer.  A host
+// last World they were given, a frame buffer in device memory (tile sums) and a page-locked host
+// buffer the kernels write resolved frames into.  A host
 // that renders frame after frame of one scene (the reference's main() renders the same World
 // twice, src/main.rs:905-937) then pays for upload and allocation once.
 struct FrameCache {
@@ -100,7 +101,7 @@ struct FrameCache {
   size_t frame_cap = 0;                   // floats
   float* pinned = nullptr;                // host, page-locked
   size_t pinned_cap = 0;                  // floats
-  hipEvent_t copied[kCopyChunks] = {};
+  hipEvent_t done = nullptr;              // behind the last kernel of the share in flight
 };
 
 struct State {
@@ -612,8 +613,7 @@ int init_context(int device) {
     RT_HIP(hipEventCreate(&ctx().ev_begin[i]));
     RT_HIP(hipEventCreate(&ctx().ev_end[i]));
   }
-  for (int i = 0; i < kCopyChunks; ++i)
-    RT_HIP(hipEventCreateWithFlags(&ctx().cache.copied[i], hipEventDisableTiming));
+  RT_HIP(hipEventCreateWithFlags(&ctx().cache.done, hipEventDisableTiming));
   ctx().device = device;
   ctx().launches = 0;
   ctx().ready = true;
@@ -633,8 +633,7 @@ void destroy_context() {
     if (sl.partial) (void)hipFree(sl.partial);
   }
   FrameCache& fc = ctx().cache;
-  for (int i = 0; i < kCopyChunks; ++i)
-    if (fc.copied[i]) (void)hipEventDestroy(fc.copied[i]);
+  if (fc.done) (void)hipEventDestroy(fc.done);
   if (fc.scene) (void)rt_scene_destroy(fc.scene);
   if (fc.frame) (void)hipFree(fc.frame);
   if (fc.pinned) (void)hipHostFree(fc.pinned);
@@ -984,7 +983,7 @@ int cached_scene(const rt_request* req, const rt_scene** out) {
   return RT_OK;
 }
 
-int cached_buffers(size_t floats) {
+int cached_frame(size_t floats) {
   FrameCache& fc = ctx().cache;
   if (floats > fc.frame_cap) {
     RT_HIP(hipStreamSynchronize(ctx().stream));
@@ -994,11 +993,17 @@ int cached_buffers(size_t floats) {
     RT_HIP(hipMalloc((void**)&fc.frame, floats * sizeof(float)));
     fc.frame_cap = floats;
   }
+  return RT_OK;
+}
+
+int cached_pinned(size_t floats) {
+  FrameCache& fc = ctx().cache;
   if (floats > fc.pinned_cap) {
     RT_HIP(hipStreamSynchronize(ctx().stream));
     if (fc.pinned) RT_HIP(hipHostFree(fc.pinned));
     fc.pinned = nullptr;
     fc.pinned_cap = 0;
+    // mapped and coherent: the kernels store into it directly (the device sees it at this address)
     RT_HIP(hipHostMalloc((void**)&fc.pinned, floats * sizeof(float), hipHostMallocDefault));
     fc.pinned_cap = floats;
   }
@@ -1026,58 +1031,69 @@ struct Share {
   }
 };
 
-// Enqueue a share on the context in charge: render (resolved) into the cached device buffer,
-// then copy it to the pinned buffer in kCopyChunks pieces, an event behind each.  Returns
-// without waiting, so several devices can be given their shares one after the other.
+// Enqueue a share on the context in charge: the kernels write the resolved pixels straight into
+// the page-locked host buffer (which the device addresses like its own memory), so the frame
+// crosses PCIe once, pushed by the kernel that produces it, and no copy-engine pass follows.
+// Returns without waiting, so several devices can be given their shares one after the other.
 int enqueue_share(const rt_request* req, const rt_frame& f, const Share& sh) {
   if (sh.pixels == 0) return RT_OK;
   const rt_scene* scene = nullptr;
   if (int rc = cached_scene(req, &scene)) return rc;
-  if (int rc = cached_buffers((size_t)sh.pixels * 3)) return rc;
+  if (int rc = cached_pinned((size_t)sh.pixels * 3)) return rc;
   FrameCache& fc = ctx().cache;
   if (int rc = render_tiles_device(scene, &f, sh.tiles.data(), sh.tiles.size(), sh.pixels, 1,
-                                   fc.frame, ctx().stream))
+                                   fc.pinned, ctx().stream))
     return rc;
-  const size_t total = (size_t)sh.pixels * 3;
-  for (int k = 0; k < kCopyChunks; ++k) {
-    const size_t b = total * k / kCopyChunks, e = total * (k + 1) / kCopyChunks;
-    if (e > b)
-      RT_HIP(hipMemcpyAsync(fc.pinned + b, fc.frame + b, (e - b) * sizeof(float),
-                            hipMemcpyDeviceToHost, ctx().stream));
-    RT_HIP(hipEventRecord(fc.copied[k], ctx().stream));
-  }
+  RT_HIP(hipEventRecord(fc.done, ctx().stream));
   return RT_OK;
 }
 
-// Wait for the share's pieces as they arrive and scatter their tile rows into the caller's
-// frame (the copy of piece k+1 runs while piece k is scattered).
+// A large copy out of the pinned buffer, shared by a few threads: one core moves about 10 GB/s
+// into pageable memory, and a 1080p frame is 25 MB.
+void copy_out(float* dst, const float* src, size_t floats) {
+  constexpr size_t kPerThread = 1u << 19;   // floats (2 MiB) a thread should at least have
+  size_t parts = floats / kPerThread;
+  if (parts > 6) parts = 6;
+  if (parts < 2) {
+    memcpy(dst, src, floats * sizeof(float));
+    return;
+  }
+  std::thread helpers[5];
+  const size_t each = floats / parts;
+  for (size_t k = 1; k < parts; ++k) {
+    const size_t b = k * each, e = k + 1 == parts ? floats : b + each;
+    helpers[k - 1] = std::thread([=] { memcpy(dst + b, src + b, (e - b) * sizeof(float)); });
+  }
+  memcpy(dst, src, each * sizeof(float));
+  for (size_t k = 1; k < parts; ++k) helpers[k - 1].join();
+}
+
+// Wait for the share and scatter its tile rows from the pinned buffer into the caller's frame.
 int collect_share(const Share& sh, uint32_t image_width, float* out_rgb) {
   if (sh.pixels == 0) return RT_OK;
   FrameCache& fc = ctx().cache;
-  const size_t total = (size_t)sh.pixels * 3;
-  size_t ti = 0;        // tile being scattered
-  uint32_t row = 0;     // next row of that tile
-  for (int k = 0; k < kCopyChunks; ++k) {
-    RT_HIP(hipEventSynchronize(fc.copied[k]));
-    const size_t ready = total * (k + 1) / kCopyChunks;   // floats of the compact buffer on the host
-    while (ti < sh.tiles.size()) {
-      const rt::TileDev& t = sh.tiles[ti];
-      const size_t row_floats = (size_t)t.w * 3;
-      const size_t src = ((size_t)t.out_offset + (size_t)row * t.w) * 3;
-      if (src + row_floats > ready) break;
-      // consecutive rows of a full-width tile are contiguous on both sides: one memcpy
-      uint32_t rows = 1;
-      if (t.w == image_width) {
-        const size_t fit = (ready - src) / row_floats;
-        rows = (uint32_t)(fit < (size_t)(t.h - row) ? fit : (size_t)(t.h - row));
+  RT_HIP(hipEventSynchronize(fc.done));
+  size_t ti = 0;
+  while (ti < sh.tiles.size()) {
+    const rt::TileDev& t = sh.tiles[ti];
+    const size_t src = (size_t)t.out_offset * 3;
+    if (t.w == image_width) {
+      // full-width tiles that follow each other in the frame and in the buffer: one copy
+      size_t tj = ti + 1;
+      uint64_t rows = t.h;
+      while (tj < sh.tiles.size() && sh.tiles[tj].w == image_width &&
+             sh.dst[tj] == sh.dst[ti] + rows * image_width &&
+             sh.tiles[tj].out_offset == t.out_offset + rows * image_width) {
+        rows += sh.tiles[tj].h;
+        ++tj;
       }
-      memcpy(out_rgb + ((size_t)sh.dst[ti] + (size_t)row * image_width) * 3, fc.pinned + src,
-             row_floats * rows * sizeof(float));
-      row += rows;
-      if (row == t.h) {
-        ++ti;
-        row = 0;
-      }
+      copy_out(out_rgb + (size_t)sh.dst[ti] * 3, fc.pinned + src, (size_t)rows * image_width * 3);
+      ti = tj;
+    } else {
+      for (uint32_t row = 0; row < t.h; ++row)
+        memcpy(out_rgb + ((size_t)sh.dst[ti] + (size_t)row * image_width) * 3,
+               fc.pinned + src + (size_t)row * t.w * 3, (size_t)t.w * 3 * sizeof(float));
+      ++ti;
     }
   }
   return RT_OK;
@@ -1208,7 +1224,7 @@ int render_tiles_host(const rt_request* req, float* out_sums, bool inout, uint32
   const rt_scene* scene = nullptr;
   if (int rc = cached_scene(req, &scene)) return rc;
   const size_t bytes = (size_t)total * 3 * sizeof(float);
-  if (int rc = cached_buffers((size_t)total * 3)) return rc;
+  if (int rc = cached_frame((size_t)total * 3)) return rc;
   float* d = ctx().cache.frame;
   if (inout) {
     RT_HIP(hipMemcpyAsync(d, out_sums, bytes, hipMemcpyHostToDevice, ctx().stream));
