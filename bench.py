@@ -294,7 +294,7 @@ def main():
     flop = FLOP_PER_TEST * n_spheres * st.rays
     achieved = flop / (kernel_ms * 1e-3) * 1e-12 if kernel_ms > 0 else 0.0
 
-    kernel_name = "rt::trace_kernel<false,%s,false>" % ("true" if n_spheres > 2016 else "false")
+    kernel_name = "rt::trace_kernel<false,%s,false>" % ("true" if n_spheres > 1200 else "false")
     if rank == 0:
         samples_per_step = W * H * spp
         value = samples_per_step * args.steps / elapsed * 1e-6

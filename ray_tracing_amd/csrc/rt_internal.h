@@ -33,10 +33,11 @@ constexpr int trace_threads(bool multi, bool accel) {
 #define RT_RAYS_PER_LANE 2
 #endif
 constexpr int kRaysPerLane = RT_RAYS_PER_LANE;   // independent paths blocked into one lane
-constexpr int kQueueSlots = 20;         // deferred-candidate slots per path (u16 each)
+constexpr uint32_t kListEntries = 512;  // candidates a wave can list between two replays
 constexpr int kScanUnroll = 4;          // spheres per unrolled block of the scan
-constexpr uint32_t kChunkSpheres = 2016; // spheres resident in LDS at a time: with the read-ahead
-                                         // padding and the queues, two workgroups fill a CU's LDS
+constexpr uint32_t kChunkSpheres = 1200; // spheres resident in LDS at a time: with the read-ahead
+                                         // padding and the waves' candidate lists, two workgroups
+                                         // of kThreads fill a CU's LDS
 constexpr size_t kLdsPerWorkgroup = 160 * 1024 / 2;   // two workgroups share a CU's 160 KB
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic

@@ -92,9 +92,22 @@ struct PhaseClock {
 #endif
 
 constexpr int R = kRaysPerLane;
-constexpr int Q = kQueueSlots;
 constexpr int U = kScanUnroll;
-static_assert(Q > 2 * U + (U - 1), "queue must hold two blocks plus the scan's tail");
+// Candidates of a wave: ONE list in LDS shared by the wave's 64 lanes and R path slots.  An
+// entry names the path (slot = lane + 64 * r, in its low 7 bits when R is 2) and the sphere
+// (index local to the chunk in LDS).  Behind the list: one 64-bit word per path with the best
+// hit found so far, as a key that an integer minimum orders like World::hit does (smaller t
+// first, the later sphere at equal t), and the paths' rays (origin, a / direction), published
+// there for the replay, whose lanes test candidates of paths that other lanes own.
+constexpr uint32_t L = kListEntries;
+constexpr uint32_t kSlots = (uint32_t)(R * kWave);
+static_assert(R == 2, "an entry keeps the path slot in 7 bits: lane | r << 6");
+static_assert(L >= (uint32_t)(U * R * kWave), "an empty list must take whatever one block can add");
+// A list that holds more than this is replayed before the scan goes on.
+constexpr uint32_t kListMark = L - (uint32_t)kWave;
+constexpr size_t kWaveLdsBytes = (size_t)L * sizeof(uint32_t) + (size_t)kSlots * sizeof(unsigned long long) +
+                                 (size_t)kSlots * 2 * sizeof(float4);
+constexpr unsigned long long kNoHit = ~0ull;
 constexpr float kTMin = 0.001f;  // src/main.rs:196
 constexpr float kTMax = FLT_MAX; // f32::MAX, src/main.rs:196
 
@@ -348,7 +361,6 @@ struct Path {
   bool degenerate;       // zero / non-finite ray: every sphere goes to the literal arithmetic
   float closest;
   uint32_t best;
-  uint32_t cnt;     // queued candidates
   bool alive;
   // path
   float tr, tg, tb; // throughput
@@ -384,16 +396,32 @@ __device__ __forceinline__ void prep_segment(Path& P) {
   }
 }
 
+// The wave's candidate list, hit keys and published rays (see L above).
+struct WaveLists {
+  uint32_t* list;               // [L]
+  unsigned long long* keys;     // [kSlots]
+  float4* rays;                 // [kSlots][2]: (ox, oy, oz, a), (dx, dy, dz, -)
+  uint32_t count;               // entries in the list, wave-uniform
+  uint32_t redo_from;           // first sphere of a block whose candidates did not all fit, or kNone
+};
+
+__device__ __forceinline__ unsigned long long hit_key(float t, uint32_t index) {
+  return ((unsigned long long)__float_as_uint(t) << 32) | (0xFFFFFFFFu - index);
+}
+
 // NB spheres against the R paths of the lane.  `s[u]` = (cx, cy, cz, -k'/2), `r2[u]` = radius^2
 // (only read when STRICT).  All NB*R discriminants are evaluated first, as independent
 // instruction chains; their sign bits are folded with an integer max (a float with the sign
 // bit clear, NaN included, is a non-negative int) and ONE rarely-taken branch per block leads
-// to the code that queues the candidates: q[(r*Q + slot)*64 + lane] (u16, indices local to the
-// sphere chunk resident in LDS), in storage order per path.
+// to the code that appends the candidates to the wave's list.  `ok[r]` is the mask of lanes
+// whose path r may be listed (`okl[r]`: this lane's bit of it): alive, with a finite non-zero
+// ray (other rays take the literal loop at the end of scan_chunk).
 template <bool STRICT, int NB>
 __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&r2)[NB],
-                                           uint32_t first_index, Path (&P)[R], uint16_t* q,
-                                           uint32_t lane, bool& flush, PhaseClock& clk) {
+                                           uint32_t first_index, Path (&P)[R],
+                                           const unsigned long long (&ok)[R], const bool (&okl)[R],
+                                           WaveLists& wl, uint32_t lane, bool& flush,
+                                           PhaseClock& clk) {
   float disc[NB][R];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
@@ -441,78 +469,149 @@ __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&
 #ifdef RT_DIAG_PHASES
     clk.trig_blocks++;
 #endif
+    // One compare per (sphere, path) pair leaves the lanes with a candidate in a scalar mask;
+    // all further decisions are the scalar unit's, and only a pair that has a candidate (two
+    // of the eight, typically, with a single lane each) costs vector instructions: a ballot
+    // count gives every such lane its place behind the list's end.
+    unsigned long long m[NB][R];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const bool trig = !(disc[u][r] < 0.0f);   // `if discriminant < 0.0 { return false }`
-        if (__builtin_amdgcn_ballot_w64(trig) != 0) {
+        // `if discriminant < 0.0 { return false }`: everything else is a candidate
+        m[u][r] = (STRICT ? __builtin_amdgcn_ballot_w64(!(disc[u][r] < 0.0f))
+                          : __builtin_amdgcn_ballot_w64(__float_as_int(disc[u][r]) >= 0)) & ok[r];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const unsigned long long mm = m[u][r];
+        if (mm != 0) {
 #ifdef RT_DIAG_PHASES
           clk.trig_pairs++;
 #endif
-          if (trig && P[r].alive) {
-            q[(r * Q + P[r].cnt) * kWave + lane] = (uint16_t)(first_index + u);
-            P[r].cnt++;
+          const uint32_t k = (uint32_t)__builtin_popcountll(mm);
+          if (__builtin_expect(wl.count + k > L, 0)) {
+            // no room: replay what the list holds, then scan this block again (an entry that
+            // gets listed twice that way changes nothing: the minimum is idempotent)
+            if (first_index < wl.redo_from) wl.redo_from = first_index;
+          } else {
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+            // (first_index + u) << 7 | r << 6 | lane
+            const bool listed = (STRICT ? !(disc[u][r] < 0.0f) : __float_as_int(disc[u][r]) >= 0) && okl[r];
+            if (listed) wl.list[wl.count + at] = lane | (((first_index + u) * R + r) << 6);
+            wl.count = __builtin_amdgcn_readfirstlane(wl.count + k);
           }
         }
       }
     }
-    // The scan loop looks at `flush` once per TWO blocks, and two blocks add at most 2*U
-    // entries per path.  Asking for a replay as soon as a queue holds Q - 2*U entries keeps
-    // every queue within its Q slots: a path enters a loop iteration with fewer than Q - 2*U.
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (__builtin_amdgcn_ballot_w64(P[r].cnt >= (uint32_t)(Q - 2 * U)) != 0) flush = true;
+    if (wl.count > kListMark || wl.redo_from != kNone) flush = true;
   }
 }
 
-__device__ __forceinline__ void replay_queue(Path (&P)[R], const float4* sph, const float* sr2,
-                                             uint32_t chunk_base, const uint16_t* q, uint32_t lane,
+// The exact test of one candidate for a path whose best hit so far is `closest`: the accepted
+// root of Sphere::hit (src/main.rs:128-150) or nothing, by candidate_hit's arithmetic and
+// filters.  Whether it replaces the path's hit is decided by the key minimum, which also
+// implements the tie rule.
+__device__ __forceinline__ bool candidate_root(float4 s, V3 o, V3 d, float a, float closest,
+                                               float* root_out) {
+  const ReplayBounds rb = replay_bounds(closest, a);
+  V3 oc = sub(o, mk(s.x, s.y, s.z));
+  float half_b = dot(oc, d);
+  float c = dot(oc, oc) - s.w;   // s.w = radius * radius
+  float discriminant = half_b * half_b - a * c;
+  if (discriminant < 0.0f) return false;
+  if (half_b > 0.0f && c > 0.0f) return false;                                            // (i)
+  const float s_hi = __builtin_amdgcn_sqrtf(discriminant) * 1.00000095367431640625f;
+  if ((-half_b - s_hi) * 0.99999904632568359375f > rb.closest_a) return false;            // (ii)
+  if ((-half_b + s_hi) * 1.00000190734863281250f < rb.tmin_a) return false;               // (iii)
+  float sqrtd = __builtin_sqrtf(discriminant);
+  float root = (-half_b - sqrtd) / a;
+  if (root < kTMin) {
+    root = (-half_b + sqrtd) / a;
+    if (root < kTMin) return false;
+  }
+  if (!(root <= closest)) return false;   // `t_max < root` rejects; NaN is never a hit
+  *root_out = root;
+  return true;
+}
+
+// Replay the wave's candidate list through the exact arithmetic.  The entries are dealt to the
+// 64 lanes in turn, so every lane has work in every trip whichever paths the candidates belong
+// to (a lane that replayed only its own candidates waited for the longest queue of its wave: a
+// third of the lanes were busy).  A lane reads the ray of the entry's path from LDS, prunes
+// against that path's best hit so far (read from its key; a stale value only prunes less) and
+// folds an accepted root into the key with an LDS atomic minimum, which does not depend on the
+// order of arrival.
+__device__ __forceinline__ void replay_lists(Path (&P)[R], const float4* sph, const float* sr2,
+                                             uint32_t chunk_base, WaveLists& wl, uint32_t lane,
                                              PhaseClock& clk) {
+  const uint32_t n = wl.count;
+  if (n == 0) return;   // wave-uniform
+#ifdef RT_DIAG_PHASES
+  if (lane == 0) clk.cand += n;   // summed over lanes at the end
+#endif
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const uint32_t n = P[r].cnt;
-    const V3 o = mk(P[r].ox, P[r].oy, P[r].oz), d = mk(P[r].dx, P[r].dy, P[r].dz);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(P[r].degenerate && n != 0) != 0, 0)) {
-      // some lane carries a zero or non-finite ray: the whole wave takes the literal loop,
-      // first to last, which is the reference for every ray
-      for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0; ++k) {
-        if (k < n) {
-          const uint32_t li = q[(r * Q + k) * kWave + lane];
-          float4 rec = sph[li];
-          rec.w = sr2[li];
-          exact_hit(rec, chunk_base + li, o, d, P[r].a, P[r].closest, P[r].best);
-        }
-      }
-    } else {
-      ReplayBounds rb = replay_bounds(P[r].closest, P[r].a);
-#ifdef RT_DIAG_PHASES
-      clk.cand += n;
-#endif
-      for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(k < n) != 0; ++k) {
-#ifdef RT_DIAG_PHASES
-        clk.replay_iters++;
-#endif
-        if (k < n) {
-          const uint32_t li = q[(r * Q + (n - 1 - k)) * kWave + lane];   // last to first
-          float4 rec = sph[li];
-          rec.w = sr2[li];
-          candidate_hit(rec, chunk_base + li, o, d, P[r].a, rb, P[r].closest, P[r].best);
-        }
-      }
-    }
-    P[r].cnt = 0;
+    const uint32_t slot = (uint32_t)r * kWave + lane;
+    wl.rays[2 * slot] = make_float4(P[r].ox, P[r].oy, P[r].oz, P[r].a);
+    wl.rays[2 * slot + 1] = make_float4(P[r].dx, P[r].dy, P[r].dz, 0.0f);
+    wl.keys[slot] = P[r].best == kNone ? kNoHit : hit_key(P[r].closest, P[r].best);
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (uint32_t j = 0; j < n; j += kWave) {
+#ifdef RT_DIAG_PHASES
+    clk.replay_iters++;
+#endif
+    if (j + lane < n) {
+      const uint32_t e = wl.list[j + lane];
+      const uint32_t slot = e & (kSlots - 1), li = e >> 7;
+      const float4 ro = wl.rays[2 * slot], rd = wl.rays[2 * slot + 1];
+      const unsigned long long now = wl.keys[slot];
+      const float closest = now == kNoHit ? kTMax : __uint_as_float((uint32_t)(now >> 32));
+      float4 rec = sph[li];
+      rec.w = sr2[li];
+      float root;
+      if (candidate_root(rec, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), ro.w, closest, &root))
+        atomicMin(&wl.keys[slot], hit_key(root, chunk_base + li));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const unsigned long long mine = wl.keys[(uint32_t)r * kWave + lane];
+    if (mine != kNoHit) {
+      P[r].closest = __uint_as_float((uint32_t)(mine >> 32));
+      P[r].best = 0xFFFFFFFFu - (uint32_t)mine;
+    }
+  }
+  wl.count = 0;
 }
 
 // Scan one LDS-resident chunk of `cn` spheres for all paths of the wave.
 template <bool STRICT>
 __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, const float* sr2,
-                                           uint32_t cn, uint32_t chunk_base, uint16_t* q,
+                                           uint32_t cn, uint32_t chunk_base, WaveLists& wl,
                                            uint32_t lane, PhaseClock& clk) {
+  // the lanes whose path r can be listed: alive, and with a finite non-zero ray
+  unsigned long long ok[R];
+  bool okl[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    okl[r] = P[r].alive && !P[r].degenerate;
+    ok[r] = __builtin_amdgcn_ballot_w64(okl[r]);
+  }
   uint32_t i = 0;
   while (i < cn) {
     bool flush = false;
+    wl.redo_from = kNone;
     RT_MARK("scan");
     RT_PRIO_SCAN();
     // The records of the next block are read from LDS while the current one is evaluated,
@@ -533,32 +632,51 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
         rB[u] = STRICT ? sr2[i + U + u] : 0.0f;
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the read-ahead ahead of the arithmetic
-      test_block<STRICT, U>(A, rA, i, P, q, lane, flush, clk);
+      test_block<STRICT, U>(A, rA, i, P, ok, okl, wl, lane, flush, clk);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         A[u] = sph[i + 2 * U + u];
         rA[u] = STRICT ? sr2[i + 2 * U + u] : 0.0f;
       }
       __builtin_amdgcn_sched_barrier(0);
-      test_block<STRICT, U>(B, rB, i + U, P, q, lane, flush, clk);
+      test_block<STRICT, U>(B, rB, i + U, P, ok, okl, wl, lane, flush, clk);
     }
     if (!flush && i + U <= cn) {
-      test_block<STRICT, U>(A, rA, i, P, q, lane, flush, clk);
+      test_block<STRICT, U>(A, rA, i, P, ok, okl, wl, lane, flush, clk);
       i += U;
     }
     if (!flush) {
-      for (; i < cn; ++i) {
+      for (; i < cn && !flush; ++i) {
         const float4 s1[1] = {sph[i]};
         const float r1[1] = {STRICT ? sr2[i] : 0.0f};
-        test_block<STRICT, 1>(s1, r1, i, P, q, lane, flush, clk);
+        test_block<STRICT, 1>(s1, r1, i, P, ok, okl, wl, lane, flush, clk);
       }
     }
+    if (wl.redo_from != kNone) i = wl.redo_from;   // a block that did not fit is scanned again
     RT_STAMP(clk.scan, clk.t0);
     RT_PRIO_REST();
     RT_MARK("replay");
-    replay_queue(P, sph, sr2, chunk_base, q, lane, clk);
+    replay_lists(P, sph, sr2, chunk_base, wl, lane, clk);
     RT_MARK("replay_end");
     RT_STAMP(clk.replay, clk.t0);
+  }
+  // Zero or non-finite rays were kept out of the lists: World::hit's loop as written
+  // (src/main.rs:175-189), first sphere of the chunk to last, which is the reference for any ray.
+  bool odd = false;
+#pragma unroll
+  for (int r = 0; r < R; ++r) odd = odd || (P[r].alive && P[r].degenerate);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (P[r].alive && P[r].degenerate) {
+        const V3 o = mk(P[r].ox, P[r].oy, P[r].oz), d = mk(P[r].dx, P[r].dy, P[r].dz);
+        for (uint32_t k = 0; k < cn; ++k) {
+          float4 rec = sph[k];
+          rec.w = sr2[k];
+          exact_hit(rec, chunk_base + k, o, d, P[r].a, P[r].closest, P[r].best);
+        }
+      }
+    }
   }
 }
 
@@ -572,12 +690,12 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
 // pass, through the exact test; the group then takes the minimum t, the larger index winning a tie
 // like a later sphere does in World::hit's loop.  A step costs n_spheres / g cheap tests per lane.
 // The paths' rays travel to their groups, and the results back, through `xch`, the wave's own
-// candidate-queue memory (idle while nothing is scanned).
+// candidate-list memory (idle while nothing is scanned).
 // IN_LDS: the whole scene is resident in the workgroup's LDS (records in `sph`, radius^2 in
 // `sr2`); a chunked scene is read from global memory.
 constexpr int kTailFloats = 12;   // ox oy oz dx dy dz a ndx ndy ndz od noo
-static_assert((kTailFloats + 2) * kWave * sizeof(float) <= (size_t)R * Q * kWave * sizeof(uint16_t),
-              "the tail exchange must fit the wave's candidate queues");
+static_assert((kTailFloats + 2) * kWave * sizeof(float) <= kWaveLdsBytes,
+              "the tail exchange must fit the wave's candidate lists");
 static_assert(kTailPaths <= (uint32_t)kWave, "one group of lanes per live path");
 
 template <bool STRICT, bool IN_LDS>
@@ -967,10 +1085,17 @@ void trace_kernel(const TraceParams p) {
   const uint32_t cap = lds_capacity(n);
   float4* sph = lds;                                       // (cx, cy, cz, -k'/2) per sphere
   float* sr2 = reinterpret_cast<float*>(lds + cap);        // radius^2 per sphere
-  uint16_t* qall = reinterpret_cast<uint16_t*>(sr2 + cap);
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = threadIdx.x / kWave;
-  uint16_t* q = qall + wave * (R * Q * kWave);
+  // this wave's candidate lists and hit keys, behind the sphere records
+  unsigned char* wave_lds = reinterpret_cast<unsigned char*>(sr2 + cap) + wave * kWaveLdsBytes;
+  WaveLists wl;
+  wl.list = reinterpret_cast<uint32_t*>(wave_lds);
+  wl.keys = reinterpret_cast<unsigned long long*>(wave_lds + (size_t)L * sizeof(uint32_t));
+  wl.rays = reinterpret_cast<float4*>(wave_lds + (size_t)L * sizeof(uint32_t) +
+                                      (size_t)kSlots * sizeof(unsigned long long));
+  wl.count = 0;
+  wl.redo_from = kNone;
 
   if (!MULTI && !ACCEL) {
     stage_chunk(p.scene, 0, n, sph, sr2);
@@ -1005,7 +1130,6 @@ void trace_kernel(const TraceParams p) {
     P[r].alive = false;
     P[r].has_item = false;
     P[r].sample = P[r].sample_end = 0;
-    P[r].cnt = 0;
     P[r].ox = P[r].oy = P[r].oz = 0.0f;
     P[r].dx = P[r].dy = P[r].dz = 0.0f;
     P[r].a = 1.0f;
@@ -1059,7 +1183,6 @@ void trace_kernel(const TraceParams p) {
     for (int r = 0; r < RP; ++r) {
       P[r].closest = kTMax;
       P[r].best = kNone;
-      P[r].cnt = 0;
     }
     // Out of work and nearly drained: trace what is left spheres-across-lanes (tail_hit).
     // Zero or non-finite rays keep to the scan, whose replay has the literal fallback.
@@ -1087,12 +1210,12 @@ void trace_kernel(const TraceParams p) {
         __syncthreads();   // every wave is done with the previous chunk
         stage_chunk(p.scene, base, cn, sph, sr2);
         __syncthreads();
-        if (!tail) scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
+        if (!tail) scan_chunk<STRICT>(P, sph, sr2, cn, base, wl, lane, clk);
       }
-      if (tail) tail_hit<STRICT, false>(P, p.scene, sph, sr2, reinterpret_cast<float*>(q), lane);
+      if (tail) tail_hit<STRICT, false>(P, p.scene, sph, sr2, reinterpret_cast<float*>(wl.list), lane);
     } else {
-      if (tail) tail_hit<STRICT, true>(P, p.scene, sph, sr2, reinterpret_cast<float*>(q), lane);
-      else scan_chunk<STRICT>(P, sph, sr2, n, 0, q, lane, clk);
+      if (tail) tail_hit<STRICT, true>(P, p.scene, sph, sr2, reinterpret_cast<float*>(wl.list), lane);
+      else scan_chunk<STRICT>(P, sph, sr2, n, 0, wl, lane, clk);
     }
 #ifdef RT_DIAG_PHASES
     if (tail) clk.tail_steps++;
@@ -1262,10 +1385,17 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   float4* sph = lds;
   constexpr uint32_t cap = lds_capacity(kChunkSpheres);
   float* sr2 = reinterpret_cast<float*>(lds + cap);
-  uint16_t* qall = reinterpret_cast<uint16_t*>(sr2 + cap);
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = threadIdx.x / kWave;
-  uint16_t* q = qall + wave * (R * Q * kWave);
+  // this wave's candidate lists and hit keys, behind the sphere records
+  unsigned char* wave_lds = reinterpret_cast<unsigned char*>(sr2 + cap) + wave * kWaveLdsBytes;
+  WaveLists wl;
+  wl.list = reinterpret_cast<uint32_t*>(wave_lds);
+  wl.keys = reinterpret_cast<unsigned long long*>(wave_lds + (size_t)L * sizeof(uint32_t));
+  wl.rays = reinterpret_cast<float4*>(wave_lds + (size_t)L * sizeof(uint32_t) +
+                                      (size_t)kSlots * sizeof(unsigned long long));
+  wl.count = 0;
+  wl.redo_from = kNone;
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   const bool live = i < p.n_rays;
 
@@ -1273,7 +1403,6 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     P[r].alive = false;
-    P[r].cnt = 0;
     P[r].ox = P[r].oy = P[r].oz = 0.0f;
     P[r].dx = P[r].dy = P[r].dz = 0.0f;
     P[r].a = 1.0f;
@@ -1305,7 +1434,7 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
       stage_chunk(p.scene, base, cn, sph, sr2);
       __syncthreads();
       PhaseClock clk = {};
-      scan_chunk<STRICT>(P, sph, sr2, cn, base, q, lane, clk);
+      scan_chunk<STRICT>(P, sph, sr2, cn, base, wl, lane, clk);
     }
   }
   if (!live) return;
@@ -1345,8 +1474,12 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
 }
 
 constexpr size_t queue_bytes(int threads) {
-  return (size_t)threads * R * Q * sizeof(uint16_t);
+  return (size_t)(threads / kWave) * kWaveLdsBytes;
 }
+// the chunked kernel's workgroup: records of one chunk, the waves' lists, 256 bytes of statics
+static_assert((size_t)lds_capacity(kChunkSpheres + 1) * (sizeof(float4) + sizeof(float)) +
+                      queue_bytes(kThreads) + 256 <= kLdsPerWorkgroup,
+              "two workgroups of the chunked kernel must fit into a CU's LDS");
 
 }  // namespace
 

@@ -1,6 +1,6 @@
 """The benchmark configurations' own workloads on the GPU.
 
- * the 10 004-sphere brute-force scene (the scan streams it through LDS in five chunks):
+ * the 10 004-sphere brute-force scene (the scan streams it through LDS in nine chunks):
    per-ray records and a small image against the oracle, bit for bit, then the full
    1920x1080 @ 64 spp frame through properties that do not depend on size;
  * 3840x2160 @ 500 spp: the frame's own sample-slice plan (body + taper), the eight row
@@ -51,9 +51,10 @@ def test_10k_brute_force_scan_per_ray_matches_world_hit(world10k):
             assert np.array_equal(got[f], ref[f]), (flags, f)
         for f in FLOAT_FIELDS:
             assert np.array_equal(got[f].view(np.uint32), ref[f].view(np.uint32)), (flags, f)
-    # hits spread over all five chunks of 2016 spheres
+    # hits spread over the chunks of 1200 spheres, the first and the last among them
     hit = ref["sphere"][ref["hit"] == 1]
-    assert set(np.unique(hit // 2016)) == {0, 1, 2, 3, 4}
+    chunks = set(int(c) for c in np.unique(hit // 1200))
+    assert {0, 8} <= chunks and len(chunks) >= 6, chunks
     scene.close()
 
 

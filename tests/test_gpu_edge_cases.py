@@ -50,7 +50,7 @@ def test_tile_shapes(tile):
     check(s, m, 33, 21, 2, tile=tile)
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 5, 2015, 2016, 2017, 4032, 4033])
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 1199, 1200, 1201, 2016, 2400, 2401, 4033])
 def test_sphere_counts_around_the_lds_chunk(n):
     s, m = O.random_world(1, -33, 33)        # 4360 spheres to cut from
     keep = np.r_[len(s) - 4:len(s), 0:len(s) - 4][:n]   # the four big ones first
