@@ -178,10 +178,12 @@ int acquire_slot(hipStream_t stream, LaunchSlot** out) {
 //
 // The scan decides which spheres get the reference's exact Sphere::hit arithmetic.  It evaluates
 //     disc' = hb'^2 - c',   hb' = o.dn - c.dn,   c' = k' - 2 o.c + |o|^2 (1 - 2^-17)
-// (the record stores -k'/2 so that the kernel can use o itself instead of -2 o; the halving and
-// doubling are exact)
 // with dn = d/|d| (slightly lengthened), i.e. the reference's discriminant divided by |d|^2 and
-// expanded so that no o - c subtraction is needed (8 instead of 11 vector instructions).  The
+// expanded so that no o - c subtraction is needed.  The kernel works on disc'/2, as
+//     (hb'/sqrt 2)^2 + (c.o - k'/2)   compared with   |o|^2 (1 - 2^-17) / 2
+// (the record stores -k'/2, the per-ray direction carries the 1/sqrt 2; the halvings are exact
+// and scale every term and every rounding error alike): 7 fused instructions and a compare
+// instead of the 11 of the literal form, and one rounding fewer than disc' itself.  The
 // expansion rounds differently from src/main.rs:131-135, so k' carries a slack that makes the
 // scan CONSERVATIVE: with u = 2^-24, the reference's computed discriminant is within
 // 22u |d|^2 (|o-c|^2 + r^2) of the exact one and the scan's within 24.3u (|o|+|c|)^2 + 4u r^2, so

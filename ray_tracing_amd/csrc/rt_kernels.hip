@@ -18,16 +18,18 @@
 //    in the reference's order from the counter stream of rt_rng.h.
 //  * World::hit is split in two.  The scan evaluates, for every sphere, only the sign of the
 //    discriminant half_b^2 - a*c of src/main.rs:131-135 (17 flops as written there).  It does so
-//    on an expanded, pre-normalised form, hb' = o.dn - c.dn and c' = k' - 2 o.c + |o|^2, which
-//    needs no o - c subtraction: 8 fused VALU instructions per ray/sphere pair.  The sphere
-//    record (cx,cy,cz,-k'/2) is one wave-uniform 16-byte LDS read shared by both paths of every
-//    lane.  k' and |o|^2 carry a slack that bounds the rounding of both forms, so the scan never
-//    skips a sphere the reference's own arithmetic would accept (derivation: trigger_constant in
-//    rt_api.cpp).  A sphere that passes is appended to a small per-path queue in LDS.  After
-//    the scan each lane replays its own queue through the reference's exact Sphere::hit
-//    arithmetic (IEEE sqrt and divide, no contraction) in storage order, so the closest-hit
-//    decision and t are bit-for-bit the reference's.  Replaying per lane keeps all 64 lanes
-//    busy in the slow part instead of one lane per triggering sphere.
+//    on an expanded, pre-normalised and halved form: with hb' = (o.dn - c.dn) / sqrt 2 and
+//    qh = c.o - k'/2, the sphere is a candidate unless hb'^2 + qh < |o|^2 / 2.  That needs no
+//    o - c subtraction and leaves no per-ray term to add: 7 fused VALU instructions and one
+//    compare per ray/sphere pair.  The sphere record (cx,cy,cz,-k'/2) is one wave-uniform
+//    16-byte LDS read shared by both paths of every lane.  k' and |o|^2 carry a slack that
+//    bounds the rounding of both forms, so the scan never skips a sphere the reference's own
+//    arithmetic would accept (derivation: trigger_constant in rt_api.cpp).  A sphere that passes
+//    is appended to the wave's candidate list in LDS.  After the scan the list is replayed
+//    through the reference's exact Sphere::hit arithmetic (IEEE sqrt and divide, no
+//    contraction), its entries dealt evenly to the 64 lanes whichever path they belong to; the
+//    closest hit of a path is the minimum of (t, later sphere first) keys, which is the decision
+//    World::hit's loop makes in storage order, so hit and t are bit-for-bit the reference's.
 //  * Scenes larger than kChunkSpheres are streamed through the same LDS buffer chunk by chunk
 //    by the whole workgroup (MULTI = true), carrying closest-hit across chunks.
 //  * When a wave has no work left and at most kTailPaths paths are still alive it stops scanning
@@ -355,9 +357,9 @@ struct Path {
   float dx, dy, dz;
   float a;          // dir.length_squared(), src/main.rs:132
   // constants of the conservative scan for this segment (prep_segment)
-  float ndx, ndy, ndz;   // -d / |d|, lengthened by 2^-20
+  float ndx, ndy, ndz;   // -d / (|d| sqrt 2), lengthened by 2^-20
   float od;              // o . (d / |d|)
-  float noo;             // -|o|^2 (1 - 2^-17)
+  float thr;             // |o|^2 (1 - 2^-17) / 2: a sphere is a candidate unless hb'^2 + qh < thr
   bool degenerate;       // zero / non-finite ray: every sphere goes to the literal arithmetic
   float closest;
   uint32_t best;
@@ -377,22 +379,28 @@ struct Path {
 
 // Constants of the conservative scan for the segment now in (o, d, a).
 __device__ __forceinline__ void prep_segment(Path& P) {
-  // 1/|d|: v_rsq_f32 is good to 1 ulp; lengthening dn by 2^-20 keeps hb'^2 from coming out low.
-  const float s = __builtin_amdgcn_rsqf(P.a) * 1.00000095367431640625f;
+  // The scan evaluates HALF the normalised discriminant, hb'^2 / 2 - c' / 2, as
+  // (hb' / sqrt 2)^2 + qh compared with |o|^2 (1 - 2^-17) / 2, where qh = c.o - k'/2 comes
+  // straight from the sphere record: seven fused instructions per (sphere, path) and no per-ray
+  // term left to add.  So the direction is scaled by 1 / (|d| sqrt 2): v_rsq_f32 is good to
+  // 1 ulp, and the factor below is (1 + 2^-20) / sqrt 2 rounded up, which keeps hb'^2 / 2 from
+  // coming out low after the three roundings involved.
+  const float s = __builtin_amdgcn_rsqf(P.a) * 0.7071074843406677f;
   const float dnx = P.dx * s, dny = P.dy * s, dnz = P.dz * s;
   P.ndx = -dnx; P.ndy = -dny; P.ndz = -dnz;
   P.od = __builtin_fmaf(P.oz, dnz, __builtin_fmaf(P.oy, dny, P.ox * dnx));
   const float oo = P.ox * P.ox + P.oy * P.oy + P.oz * P.oz;
-  P.noo = -(oo * 0.99999237060546875f);   // 1 - 2^-17
+  P.thr = (oo * 0.99999237060546875f) * 0.5f;   // 1 - 2^-17; the halving is exact
   // A direction of zero, infinite or NaN length, or an origin that is not finite: the scan's
-  // algebra does not apply, so make it pass every sphere on to the exact arithmetic (which
-  // then does whatever the reference does with such a ray).  hb' = +inf, -c' = +inf.
+  // algebra does not apply.  Such a ray is kept out of the candidate lists and takes the
+  // literal loop over all spheres (which then does whatever the reference does with it); a
+  // threshold of -inf makes every filter that uses these constants pass every sphere on.
   const float inf = __builtin_inff();
   P.degenerate = !(P.a > 0.0f) || !(P.a < inf) || !(oo < 1e37f) || !(__builtin_fabsf(P.od) < inf);
   if (P.degenerate) {
     P.ndx = P.ndy = P.ndz = 0.0f;
-    P.od = inf;
-    P.noo = inf;
+    P.od = 0.0f;
+    P.thr = -inf;
   }
 }
 
@@ -410,19 +418,20 @@ __device__ __forceinline__ unsigned long long hit_key(float t, uint32_t index) {
 }
 
 // NB spheres against the R paths of the lane.  `s[u]` = (cx, cy, cz, -k'/2), `r2[u]` = radius^2
-// (only read when STRICT).  All NB*R discriminants are evaluated first, as independent
-// instruction chains; their sign bits are folded with an integer max (a float with the sign
-// bit clear, NaN included, is a non-negative int) and ONE rarely-taken branch per block leads
-// to the code that appends the candidates to the wave's list.  `ok[r]` is the mask of lanes
-// whose path r may be listed (`okl[r]`: this lane's bit of it): alive, with a finite non-zero
-// ray (other rays take the literal loop at the end of scan_chunk).
+// (only read when STRICT).  All NB*R values are evaluated first, as independent instruction
+// chains; one compare each (`not below the path's threshold`, so that a NaN counts as a
+// candidate, as it does in `if discriminant < 0.0 { return false }`) leaves the lanes with a
+// candidate in NB*R scalar masks, which the scalar unit ORs together: ONE rarely-taken branch
+// per block leads to the code that appends the candidates to the wave's list.  `ok[r]` is the
+// mask of lanes whose path r may be listed (`okl[r]`: this lane's bit of it): alive, with a
+// finite non-zero ray (other rays take the literal loop at the end of scan_chunk).
 template <bool STRICT, int NB>
 __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&r2)[NB],
                                            uint32_t first_index, Path (&P)[R],
                                            const unsigned long long (&ok)[R], const bool (&okl)[R],
                                            WaveLists& wl, uint32_t lane, bool& flush,
                                            PhaseClock& clk) {
-  float disc[NB][R];
+  float v[NB][R];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
 #pragma unroll
@@ -431,63 +440,48 @@ __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&
         const float ocx = P[r].ox - s[u].x, ocy = P[r].oy - s[u].y, ocz = P[r].oz - s[u].z;
         const float half_b = (ocx * P[r].dx + ocy * P[r].dy) + ocz * P[r].dz;
         const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - r2[u];
-        disc[u][r] = half_b * half_b - P[r].a * c;
-      } else {        // conservative expanded form, 8 instructions
+        v[u][r] = half_b * half_b - P[r].a * c;
+      } else {        // conservative expanded form, 7 instructions (see prep_segment)
         const float hb = __builtin_fmaf(s[u].z, P[r].ndz,
                          __builtin_fmaf(s[u].y, P[r].ndy, __builtin_fmaf(s[u].x, P[r].ndx, P[r].od)));
-        // s.w = -k'/2, so qh = c.o - k'/2 and -c' = 2 qh - |o|^2(1 - 2^-17)
+        // s.w = -k'/2, so qh = c.o - k'/2
         const float qh = __builtin_fmaf(s[u].z, P[r].oz,
                          __builtin_fmaf(s[u].y, P[r].oy, __builtin_fmaf(s[u].x, P[r].ox, s[u].w)));
-        disc[u][r] = __builtin_fmaf(hb, hb, __builtin_fmaf(qh, 2.0f, P[r].noo));
+        v[u][r] = __builtin_fmaf(hb, hb, qh);
       }
     }
   }
-  bool any;
-  if (STRICT) {
-    // literal mode keeps the float comparison: a discriminant that is NaN of either sign, or
-    // -0.0, is "not less than zero" in the reference
-    any = false;
+  // the literal form compares the discriminant with zero, as the reference does
+  unsigned long long m[NB][R], hot[R];
 #pragma unroll
-    for (int u = 0; u < NB; ++u)
+  for (int r = 0; r < R; ++r) {
+    const float thr = STRICT ? 0.0f : P[r].thr;
+    hot[r] = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) any = any || !(disc[u][r] < 0.0f);
-  } else {
-    // prep_segment keeps NaN out of the per-ray constants and rt_scene_create keeps it out of
-    // the records, and a fused multiply-add cannot produce -0.0 here, so "sign bit clear" is
-    // exactly "not less than zero"
-    int m = (int)0x80000000;
-#pragma unroll
-    for (int u = 0; u < NB; ++u)
-#pragma unroll
-      for (int r = 0; r < R; ++r) m = max(m, __float_as_int(disc[u][r]));
-    any = m >= 0;
+    for (int u = 0; u < NB; ++u) {
+      m[u][r] = __builtin_amdgcn_ballot_w64(!(v[u][r] < thr));
+      hot[r] |= m[u][r];
+    }
+    hot[r] &= ok[r];
   }
+  unsigned long long any = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) any |= hot[r];
 #ifdef RT_DIAG_PHASES
   clk.blocks++;
 #endif
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(any) != 0, 0)) {
+  if (__builtin_expect(any != 0, 0)) {
 #ifdef RT_DIAG_PHASES
     clk.trig_blocks++;
 #endif
-    // One compare per (sphere, path) pair leaves the lanes with a candidate in a scalar mask;
-    // all further decisions are the scalar unit's, and only a pair that has a candidate (two
+    // All further decisions are the scalar unit's, and only a pair that has a candidate (two
     // of the eight, typically, with a single lane each) costs vector instructions: a ballot
     // count gives every such lane its place behind the list's end.
-    unsigned long long m[NB][R];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        // `if discriminant < 0.0 { return false }`: everything else is a candidate
-        m[u][r] = (STRICT ? __builtin_amdgcn_ballot_w64(!(disc[u][r] < 0.0f))
-                          : __builtin_amdgcn_ballot_w64(__float_as_int(disc[u][r]) >= 0)) & ok[r];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const unsigned long long mm = m[u][r];
+        const unsigned long long mm = m[u][r] & ok[r];
         if (mm != 0) {
 #ifdef RT_DIAG_PHASES
           clk.trig_pairs++;
@@ -501,7 +495,7 @@ __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&
             const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
             // (first_index + u) << 7 | r << 6 | lane
-            const bool listed = (STRICT ? !(disc[u][r] < 0.0f) : __float_as_int(disc[u][r]) >= 0) && okl[r];
+            const bool listed = !(v[u][r] < (STRICT ? 0.0f : P[r].thr)) && okl[r];
             if (listed) wl.list[wl.count + at] = lane | (((first_index + u) * R + r) << 6);
             wl.count = __builtin_amdgcn_readfirstlane(wl.count + k);
           }
@@ -686,14 +680,14 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
 // the launch open.  Here the live paths are packed and the SPHERES are spread over lanes instead:
 // with n live paths, the wave is cut into groups of g = 64 / pow2(n) lanes, one group per path;
 // lane j of a group takes spheres j, j+g, ... first through the scan's conservative
-// discriminant (8 fused instructions; the literal arithmetic when STRICT) and, for the few that
+// discriminant (7 fused instructions; the literal arithmetic when STRICT) and, for the few that
 // pass, through the exact test; the group then takes the minimum t, the larger index winning a tie
 // like a later sphere does in World::hit's loop.  A step costs n_spheres / g cheap tests per lane.
 // The paths' rays travel to their groups, and the results back, through `xch`, the wave's own
 // candidate-list memory (idle while nothing is scanned).
 // IN_LDS: the whole scene is resident in the workgroup's LDS (records in `sph`, radius^2 in
 // `sr2`); a chunked scene is read from global memory.
-constexpr int kTailFloats = 12;   // ox oy oz dx dy dz a ndx ndy ndz od noo
+constexpr int kTailFloats = 12;   // ox oy oz dx dy dz a ndx ndy ndz od thr
 static_assert((kTailFloats + 2) * kWave * sizeof(float) <= kWaveLdsBytes,
               "the tail exchange must fit the wave's candidate lists");
 static_assert(kTailPaths <= (uint32_t)kWave, "one group of lanes per live path");
@@ -715,7 +709,7 @@ __device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, const
       f[3 * kWave] = P[r].dx; f[4 * kWave] = P[r].dy; f[5 * kWave] = P[r].dz;
       f[6 * kWave] = P[r].a;
       f[7 * kWave] = P[r].ndx; f[8 * kWave] = P[r].ndy; f[9 * kWave] = P[r].ndz;
-      f[10 * kWave] = P[r].od; f[11 * kWave] = P[r].noo;
+      f[10 * kWave] = P[r].od; f[11 * kWave] = P[r].thr;
     }
   }
   if (n == 0) return;
@@ -735,7 +729,7 @@ __device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, const
     const float dx = f[3 * kWave], dy = f[4 * kWave], dz = f[5 * kWave];
     const float a = f[6 * kWave];
     const float ndx = f[7 * kWave], ndy = f[8 * kWave], ndz = f[9 * kWave];
-    const float od = f[10 * kWave], noo = f[11 * kWave];
+    const float od = f[10 * kWave], thr = f[11 * kWave];
     ReplayBounds rb = replay_bounds(c, a);
     for (uint32_t i = sub; i < sc.n_spheres; i += g) {
       const float4 s = IN_LDS ? sph[i] : sc.trig[i];
@@ -743,8 +737,7 @@ __device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, const
         // the same filter, with the same guarantee, as test_block's conservative form
         const float hb = __builtin_fmaf(s.z, ndz, __builtin_fmaf(s.y, ndy, __builtin_fmaf(s.x, ndx, od)));
         const float qh = __builtin_fmaf(s.z, oz, __builtin_fmaf(s.y, oy, __builtin_fmaf(s.x, ox, s.w)));
-        const float disc = __builtin_fmaf(hb, hb, __builtin_fmaf(qh, 2.0f, noo));
-        if (disc < 0.0f) continue;
+        if (__builtin_fmaf(hb, hb, qh) < thr) continue;
       }
       const float4 geo = IN_LDS ? make_float4(s.x, s.y, s.z, sr2[i]) : sc.geom[i];
       candidate_hit(geo, i, mk(ox, oy, oz), mk(dx, dy, dz), a, rb, c, b);
