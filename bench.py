@@ -149,22 +149,32 @@ def drop_in_leg(hip, scene_host, camera, W, H, spp, depth, seed, steps, kernel_m
 
 def profiled_traffic(config, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/: FETCH_SIZE and WRITE_SIZE, in KiB, each collected in a pass of its own).
-    FETCH_SIZE is doubled as the gfx950 correction for wide reads prescribes, which makes the
-    figure an upper bound for this kernel's narrow reads.  None when no profile of `config` is
-    in the tree: the counters cannot be read from inside a timed run."""
+    command (profiles/: FETCH_SIZE and WRITE_SIZE, in KiB, each collected in a pass of its own),
+    and where they come from.  FETCH_SIZE is doubled as the gfx950 correction for wide reads
+    prescribes, which makes the figure an upper bound for this kernel's narrow reads.
+    (None, reason) when no profile of `config` is in the tree: the counters cannot be read from
+    inside a timed run."""
     import csv
-    path = os.path.join(ROOT, "profiles", "round1", config + "_pmc_per_launch.csv")
-    if not os.path.exists(path):
-        return None
+    for rnd in ("round2", "round1"):
+        path = os.path.join(ROOT, "profiles", rnd, config + "_pmc_per_launch.csv")
+        if os.path.exists(path):
+            break
+    else:
+        return None, "no committed PMC profile of this configuration"
     kib = {}
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             if row["kernel"] == kernel and row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 kib[row["counter"]] = float(row["value_per_launch"])
+    rel = os.path.relpath(path, ROOT)
     if len(kib) != 2:
-        return None
-    return int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024)
+        return None, rel + " has no FETCH_SIZE / WRITE_SIZE rows for " + kernel
+    commit = ""
+    note = os.path.join(os.path.dirname(path), config + "_profiled_commit.txt")
+    if os.path.exists(note):
+        commit = ", library built from commit " + open(note).read().strip()
+    return (int((2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024),
+            "%s (rocprofv3 --pmc, bytes per launch of an earlier run of this command%s)" % (rel, commit))
 
 
 def main():
@@ -297,6 +307,8 @@ def main():
 
     kernel_name = "rt::trace_kernel<false,%s,false>" % ("true" if n_spheres > 1200 else "false")
     if rank == 0:
+        traffic, traffic_source = (profiled_traffic(args.config, kernel_name) if world == 1
+                                   else (None, "not reported for N > 1"))
         samples_per_step = W * H * spp
         value = samples_per_step * args.steps / elapsed * 1e-6
         line = {
@@ -329,10 +341,8 @@ def main():
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
-                "traffic": profiled_traffic(args.config, kernel_name) if world == 1 else None,
-                "traffic_source": "profiles/round1/%s_pmc_per_launch.csv (rocprofv3 --pmc, bytes "
-                                  "per launch of an earlier run of this command; null when that "
-                                  "file is absent or N > 1)" % args.config,
+                "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": kernel_name,
                 "kernel_ms": round(kernel_ms, 3),
                 "kernel_ms_source": kernel_ms_source,
