@@ -87,6 +87,16 @@ typedef struct rt_tile {
                                      a bound on the reference's own rounding, so the result is
                                      bit-identical to the scan's */
 
+#define RT_FLAG_SCAN_VALU 8u      /* keep the linear scan's sphere filter on the vector ALU (seven
+                                     fused f32 instructions and a compare per ray/sphere pair).
+                                     Without this flag the filter runs on the matrix pipe where
+                                     the scene allows it: the sign of the discriminant is a
+                                     bilinear form of ten numbers of the sphere and ten of the
+                                     ray, evaluated in split f16 by v_mfma_f32_16x16x32_f16 with a
+                                     slack that covers its rounding.  Either filter only chooses
+                                     which spheres get the exact arithmetic, and neither drops a
+                                     sphere that arithmetic would accept: same bits both ways */
+
 /* Mirror of `struct Dispatch` (reference src/cpu/mod.rs:19-30) plus the render seed.
  * rt_render() renders exactly the listed tiles and leaves every other pixel (0,0,0), like the
  * reference's compose_final_framebuffer (src/cpu/mod.rs:57-80); `tiles` == NULL (or a list that

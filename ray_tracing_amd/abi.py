@@ -17,6 +17,7 @@ RT_MAT_DIELECTRIC = 2
 RT_FLAG_STRICT_FP = 1
 RT_FLAG_SEQUENTIAL_SUM = 2
 RT_FLAG_ACCEL = 4
+RT_FLAG_SCAN_VALU = 8
 
 RT_KIND_MISS = 0
 RT_KIND_DIFFUSE = 1

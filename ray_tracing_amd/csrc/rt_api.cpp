@@ -7,6 +7,7 @@
 // every compute entry point fails with RT_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -32,6 +33,9 @@ struct rt_scene {
   mutable void* leaf_index = nullptr;
   mutable uint32_t bvh_depth = 0;
   mutable bool bvh_built = false;
+  void* mfma_rows = nullptr;    // the matrix scan's copy of the scene (build_mfma_scene)
+  void* mfma_geom = nullptr;
+  void* mfma_index = nullptr;
   int device = -1;
   // host copies: what the hierarchy is built from, and what rt_render compares a request's
   // world with to decide whether the device copy it kept from the last call still serves
@@ -200,6 +204,159 @@ float trigger_constant(const rt_sphere& s) {
   return -0.5f * kf;
 }
 
+// ---- the scene as the matrix scan reads it (scan_chunk_mfma in rt_kernels.hip) -----------------
+// Per sphere one row of 32 f16: the ten numbers of the bilinear form in two halves each (k in
+// three), laid out to meet the ray's column slot by slot, by quarters of 8 slots, in chunks of
+// kMfmaChunk spheres padded by one block of rows that no ray passes.
+// Order: the spheres inside the filter's range sorted along a Morton curve through their centres
+// (neighbours in space share a block of 16 rows, so the rays of a wave, which travel together,
+// find their candidates in few blocks), then the spheres outside it, which have no row and are
+// listed for every ray.  A sphere is outside when it is one of at most kMfmaMaxAlways that stand
+// a factor 4 above the rest in max(|c|, r), like the ground of the reference's scenes: the scale
+// (a power of two, exact on every coordinate) is chosen so that the rest sits below 128.
+struct MfmaScene {
+  bool ok = false;
+  float scale = 1.0f;
+  uint32_t n_always = 0;
+  std::vector<uint16_t> rows;      // f16 bit patterns, [chunk][4][kMfmaRows][8]
+  std::vector<float4> geom;        // [position]
+  std::vector<uint32_t> index;     // [position]
+};
+
+uint16_t f16_bits(_Float16 h) {
+  uint16_t b;
+  memcpy(&b, &h, sizeof b);
+  return b;
+}
+
+void mfma_row_threshold(uint16_t* row) {   // what meets the three parts of the ray's -threshold
+  row[29] = f16_bits((_Float16)32768.0f);
+  row[30] = f16_bits((_Float16)32.0f);
+  row[31] = f16_bits((_Float16)0.03125f);
+}
+
+void mfma_row_never(uint16_t* row) {   // a row no ray passes: k = +60000, the rest zero
+  for (int i = 0; i < 32; ++i) row[i] = 0;
+  row[27] = f16_bits((_Float16)60000.0f);
+  mfma_row_threshold(row);
+}
+
+void mfma_row(const rt_sphere& sp, double scale, uint16_t* row) {
+  const double x = sp.x * scale, y = sp.y * scale, z = sp.z * scale, r = sp.radius * scale;
+  const double c2 = x * x + y * y + z * z, r2 = r * r, c1 = std::sqrt(c2);
+  const double S[9] = {x * x, y * y, z * z, x * y, x * z, y * z, x, y, z};
+  for (int t = 0; t < 9; ++t) {
+    const _Float16 hi = (_Float16)S[t];
+    const _Float16 lo = (_Float16)(S[t] - (double)hi);
+    row[t] = f16_bits(hi);
+    row[9 + t] = f16_bits(hi);
+    row[18 + t] = f16_bits(lo);
+  }
+  // k with the sphere side's slack taken off, in two parts that do not add up to more than k
+  const double k = c2 - r2 - std::ldexp(c2, -17) - std::ldexp(r2, -18) - std::ldexp(c2 + c1, -21);
+  _Float16 kh = (_Float16)k;
+  _Float16 kl = (_Float16)(k - (double)kh);
+  while ((double)kh + (double)kl > k) {
+    uint16_t b = f16_bits(kl);
+    // one f16 step towards -infinity
+    if (b == 0x0000) b = 0x8001; else if (b & 0x8000) b++; else b--;
+    memcpy(&kl, &b, sizeof kl);
+  }
+  row[27] = f16_bits(kh);
+  row[28] = f16_bits(kl);
+  mfma_row_threshold(row);
+}
+
+uint32_t morton10(uint32_t v) {   // spread the low 10 bits of v three apart
+  v &= 0x3FF;
+  v = (v | (v << 16)) & 0x030000FF;
+  v = (v | (v << 8)) & 0x0300F00F;
+  v = (v | (v << 4)) & 0x030C30C3;
+  v = (v | (v << 2)) & 0x09249249;
+  return v;
+}
+
+void build_mfma_scene(const rt_sphere* spheres, uint32_t n, MfmaScene* out) {
+  MfmaScene& m = *out;
+  m = MfmaScene();
+  if (n == 0) return;
+  std::vector<double> size(n);
+  std::vector<uint32_t> by_size(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const rt_sphere& s = spheres[i];
+    const double c1 = std::sqrt((double)s.x * s.x + (double)s.y * s.y + (double)s.z * s.z);
+    size[i] = std::max(c1, std::fabs((double)s.radius));
+    if (!std::isfinite(size[i])) return;
+    by_size[i] = i;
+  }
+  std::stable_sort(by_size.begin(), by_size.end(),
+                   [&](uint32_t a, uint32_t b) { return size[a] > size[b]; });
+  // the last gap of a factor 4 among the largest few separates the spheres that get no row
+  uint32_t n_always = 0;
+  for (uint32_t k = 1; k <= rt::kMfmaMaxAlways && k < n; ++k)
+    if (size[by_size[k - 1]] >= 4.0 * size[by_size[k]]) n_always = k;
+  const double bulk = size[by_size[n_always]];
+  int e = 0;
+  if (bulk > 0.0) {
+    e = (int)std::floor(std::log2(128.0 / bulk));
+    while (std::ldexp(bulk, e) > 128.0) --e;
+    if (e > 60) e = 60;
+    if (e < -60) return;
+  }
+  const double scale = std::ldexp(1.0, e);
+  std::vector<char> always(n, 0);
+  for (uint32_t k = 0; k < n_always; ++k) always[by_size[k]] = 1;
+
+  // Morton order of the others
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (uint32_t i = 0; i < n; ++i) {
+    if (always[i]) continue;
+    const double c[3] = {spheres[i].x, spheres[i].y, spheres[i].z};
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
+  }
+  std::vector<std::pair<uint32_t, uint32_t>> order;   // (code, sphere)
+  order.reserve(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    if (always[i]) continue;
+    const double c[3] = {spheres[i].x, spheres[i].y, spheres[i].z};
+    uint32_t code = 0;
+    for (int a = 0; a < 3; ++a) {
+      const double span = hi[a] - lo[a];
+      const uint32_t q = span > 0.0 ? (uint32_t)std::min(1023.0, (c[a] - lo[a]) / span * 1024.0) : 0u;
+      code |= morton10(q) << a;
+    }
+    order.push_back(std::make_pair(code, i));
+  }
+  std::sort(order.begin(), order.end());
+  m.index.reserve(n);
+  for (const auto& o : order) m.index.push_back(o.second);
+  for (uint32_t i = 0; i < n; ++i)
+    if (always[i]) m.index.push_back(i);
+
+  const uint32_t n_in = n - n_always;
+  const uint32_t chunks = (n + rt::kMfmaChunk - 1) / rt::kMfmaChunk;
+  m.rows.assign((size_t)chunks * 4 * rt::kMfmaRows * 8, 0);
+  m.geom.resize(n);
+  uint16_t row[32];
+  for (uint32_t ch = 0; ch < chunks; ++ch) {
+    for (uint32_t i = 0; i < rt::kMfmaRows; ++i) {
+      const uint32_t pos = ch * rt::kMfmaChunk + i;
+      if (i < rt::kMfmaChunk && pos < n_in) mfma_row(spheres[m.index[pos]], scale, row);
+      else mfma_row_never(row);
+      for (int q = 0; q < 4; ++q)
+        memcpy(&m.rows[(((size_t)ch * 4 + q) * rt::kMfmaRows + i) * 8], row + 8 * q, 16);
+    }
+  }
+  for (uint32_t pos = 0; pos < n; ++pos) {
+    const rt_sphere& s = spheres[m.index[pos]];
+    volatile float r2 = s.radius * s.radius;   // `self.radius * self.radius`, src/main.rs:134
+    m.geom[pos] = make_float4(s.x, s.y, s.z, r2);
+  }
+  m.scale = (float)scale;
+  m.n_always = n_always;
+  m.ok = true;
+}
+
 int check_ready() {
   if (!ctx().ready) return fail(RT_ERR_NOT_INITIALIZED, "rt_init() has not been called");
   // every call below allocates, copies or launches on the library's device, whatever device
@@ -232,7 +389,7 @@ int check_frame(const rt_frame* f) {
   if (f->samples_per_pixel == 0) return fail(RT_ERR_INVALID_ARGUMENT, "samples_per_pixel is 0");
   if ((uint64_t)f->image_width * f->image_height > 0x7FFFFFFFull)
     return fail(RT_ERR_LIMIT, "more than 2^31 pixels");
-  if (f->flags & ~(RT_FLAG_STRICT_FP | RT_FLAG_SEQUENTIAL_SUM | RT_FLAG_ACCEL))
+  if (f->flags & ~(RT_FLAG_STRICT_FP | RT_FLAG_SEQUENTIAL_SUM | RT_FLAG_ACCEL | RT_FLAG_SCAN_VALU))
     return fail(RT_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", f->flags);
   return RT_OK;
 }
@@ -327,13 +484,14 @@ int ensure_bvh(const rt_scene* s) {
 
 // Launch-geometry queries do not change for the life of the process; asking once per kernel
 // variant keeps the call path of a frame down to its launches.
-int blocks_per_cu(bool strict, bool multi, bool accel, size_t lds, int* out) {
+int blocks_per_cu(bool strict, bool multi, bool accel, bool mfma, size_t lds, int* out) {
   struct Entry { bool valid; size_t lds; int per_cu; };
-  static Entry cache[8] = {};
-  Entry& e = cache[(strict ? 1 : 0) | (multi ? 2 : 0) | (accel ? 4 : 0)];
+  static Entry cache[16] = {};
+  Entry& e = cache[(strict ? 1 : 0) | (multi ? 2 : 0) | (accel ? 4 : 0) | (mfma ? 8 : 0)];
   if (!e.valid || e.lds != lds) {
     int per_cu = 0;
-    RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, accel, lds, &per_cu));
+    if (mfma) RT_HIP(rt::trace_max_blocks_per_cu_mfma(multi, lds, &per_cu));
+    else RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, accel, lds, &per_cu));
     e.valid = true;
     e.lds = lds;
     e.per_cu = per_cu;
@@ -492,17 +650,25 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
 
   bool bvh_in_lds = false;
   p.bvh_stack = scene->bvh_depth ? scene->bvh_depth : 1;
-  const size_t lds = rt::trace_lds_bytes(scene->dev.n_spheres, accel, scene->dev.bvh_info.n_nodes,
-                                         p.bvh_stack, &bvh_in_lds);
+  // the scan's filter runs on the matrix pipe unless the request or the scene says otherwise
+  // (a camera farther out than the matrix filter's origins reach would send every primary ray
+  // through the literal loop: such a frame keeps to the vector scan as well)
+  const double cam2 = ((double)p.origin[0] * p.origin[0] + (double)p.origin[1] * p.origin[1] +
+                       (double)p.origin[2] * p.origin[2]) * scene->dev.mfma_scale * scene->dev.mfma_scale;
+  const bool mfma = !strict && !accel && !(frame->flags & RT_FLAG_SCAN_VALU) && scene->dev.mfma_ok &&
+                    cam2 < 536870912.0;   // 2^29: a quarter of the filter's limit on |o|^2
+  const size_t lds = mfma ? rt::trace_lds_bytes_mfma(rt::kThreadsMfma)
+                          : rt::trace_lds_bytes(scene->dev.n_spheres, accel, scene->dev.bvh_info.n_nodes,
+                                                p.bvh_stack, &bvh_in_lds);
   p.bvh_in_lds = bvh_in_lds ? 1 : 0;
-  const bool multi = scene->dev.n_spheres > rt::kChunkSpheres;
+  const bool multi = scene->dev.n_spheres > (mfma ? rt::kMfmaChunk : rt::kChunkSpheres);
   int per_cu = 0;
-  if (int rc = blocks_per_cu(strict, multi, accel, lds, &per_cu)) return rc;
+  if (int rc = blocks_per_cu(strict, multi, accel, mfma, lds, &per_cu)) return rc;
   if (per_cu < 1) return fail(RT_ERR_DEVICE, "trace kernel does not fit on a CU (LDS %zu B)", lds);
   int blocks = per_cu * ctx().cus;
   const uint32_t paths_per_lane = accel ? 1 : rt::kRaysPerLane;
   const uint64_t lanes_needed = ((uint64_t)p.total_items + paths_per_lane - 1) / paths_per_lane;
-  const uint32_t threads = (uint32_t)rt::trace_threads(multi, accel);
+  const uint32_t threads = (uint32_t)rt::trace_threads(multi, accel, mfma);
   const uint64_t blocks_needed = (lanes_needed + threads - 1) / threads;
   if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
   if (blocks < 1) blocks = 1;
@@ -512,7 +678,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   RT_HIP(hipMemsetAsync(slot->counters, 0, sizeof(rt::Counters), stream));
   const int ev = (int)(ctx().launches % kEventRing);
   RT_HIP(hipEventRecord(ctx().ev_begin[ev], stream));
-  RT_HIP(rt::launch_trace(p, strict, accel, blocks, stream));
+  RT_HIP(rt::launch_trace(p, strict, accel, mfma, blocks, stream));
   RT_HIP(hipEventRecord(ctx().ev_end[ev], stream));
   ctx().launches++;
 
@@ -730,6 +896,22 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
   s->dev.n_spheres = n_spheres;
   s->dev.n_materials = n_materials;
   s->dev.bvh_info = rt::BvhInfo();   // the hierarchy is built on first use (ensure_bvh)
+  MfmaScene ms;
+  build_mfma_scene(spheres, n_spheres, &ms);
+  if (ms.ok) {
+    RT_HIP(hipMalloc(&s->mfma_rows, ms.rows.size() * sizeof(uint16_t)));
+    RT_HIP(hipMalloc(&s->mfma_geom, ms.geom.size() * sizeof(float4)));
+    RT_HIP(hipMalloc(&s->mfma_index, ms.index.size() * sizeof(uint32_t)));
+    RT_HIP(hipMemcpy(s->mfma_rows, ms.rows.data(), ms.rows.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(s->mfma_geom, ms.geom.data(), ms.geom.size() * sizeof(float4), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(s->mfma_index, ms.index.data(), ms.index.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    s->dev.mfma_rows = (const uint4*)s->mfma_rows;
+    s->dev.mfma_geom = (const float4*)s->mfma_geom;
+    s->dev.mfma_index = (const uint32_t*)s->mfma_index;
+    s->dev.mfma_ok = 1;
+    s->dev.mfma_always = ms.n_always;
+    s->dev.mfma_scale = ms.scale;
+  }
   guard.s = nullptr;
   *out_scene = s;
   return RT_OK;
@@ -743,6 +925,9 @@ int rt_scene_destroy(rt_scene* scene) {
   if (scene->geom) (void)hipFree(scene->geom);
   if (scene->aux) (void)hipFree(scene->aux);
   if (scene->mat) (void)hipFree(scene->mat);
+  if (scene->mfma_rows) (void)hipFree(scene->mfma_rows);
+  if (scene->mfma_geom) (void)hipFree(scene->mfma_geom);
+  if (scene->mfma_index) (void)hipFree(scene->mfma_index);
   if (scene->bvh) (void)hipFree(scene->bvh);
   if (scene->leaf_geom) (void)hipFree(scene->leaf_geom);
   if (scene->leaf_index) (void)hipFree(scene->leaf_index);
@@ -1310,6 +1495,7 @@ int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays,
   hp.n_rays = n_rays;
   hp.seed = seed;
   hp.accel = accel ? 1 : 0;
+  hp.mfma = !accel && !(flags & (RT_FLAG_STRICT_FP | RT_FLAG_SCAN_VALU)) && scene->dev.mfma_ok ? 1 : 0;
   RT_HIP(rt::launch_hook(hp, (flags & RT_FLAG_STRICT_FP) != 0, ctx().stream));
   RT_HIP(hipStreamSynchronize(ctx().stream));
   RT_HIP(hipMemcpy(out, dout.p, (size_t)n_rays * sizeof(rt_ray_out), hipMemcpyDeviceToHost));

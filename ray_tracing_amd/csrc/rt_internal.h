@@ -26,8 +26,15 @@ constexpr int kThreadsSingle = RT_THREADS_SINGLE;
 #define RT_THREADS_ACCEL 512
 #endif
 constexpr int kThreadsAccel = RT_THREADS_ACCEL;   // workgroup of the hierarchy traversal
-constexpr int trace_threads(bool multi, bool accel) {
-  return accel ? kThreadsAccel : multi ? kThreads : kThreadsSingle;
+// The scan on the matrix pipe: one workgroup of 16 waves per CU shares the sphere rows (64 bytes a
+// sphere), which two smaller workgroups could not both hold beside the waves' candidate lists.
+constexpr int kThreadsMfma = 1024;
+constexpr uint32_t kMfmaChunk = 512;               // spheres resident in LDS at a time
+constexpr uint32_t kMfmaBlock = 16;                // spheres per MFMA (rows of a 16x16x32 product)
+constexpr uint32_t kMfmaRows = kMfmaChunk + kMfmaBlock;   // + one block of read-ahead padding
+constexpr uint32_t kMfmaMaxAlways = 8;             // spheres out of f16 range, listed for every ray
+constexpr int trace_threads(bool multi, bool accel, bool mfma = false) {
+  return accel ? kThreadsAccel : mfma ? kThreadsMfma : multi ? kThreads : kThreadsSingle;
 }
 #ifndef RT_RAYS_PER_LANE
 #define RT_RAYS_PER_LANE 2
@@ -139,6 +146,14 @@ struct SceneDev {
   const float4* leaf_geom;
   const uint32_t* leaf_index;
   BvhInfo bvh_info;
+  // The scan on the matrix pipe (see build_mfma_scene in rt_api.cpp).  Spheres in `mfma` order:
+  // those inside the f16 range sorted along a space-filling curve, then the n_always others.
+  const uint4* mfma_rows;       // [chunk][4][kMfmaRows] x 8 f16: the spheres' rows, by quarters
+  const float4* mfma_geom;      // [position] (cx, cy, cz, r*r) for the exact replay
+  const uint32_t* mfma_index;   // [position] -> sphere number in the World
+  uint32_t mfma_ok;             // 0: this scene keeps to the vector-ALU scan
+  uint32_t mfma_always;         // the last mfma_always positions are listed for every ray
+  float mfma_scale;             // power of two applied to centres, radii and ray origins
 };
 
 struct Counters {
@@ -208,14 +223,17 @@ struct HookParams {
   uint32_t n_rays;
   uint32_t seed;
   int accel;              // World::hit through the hierarchy instead of the scan
+  int mfma;               // the scan's filter on the matrix pipe
 };
 
 // Launchers implemented in rt_kernels.hip.  `strict` selects the non-contracted discriminant.
 size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint32_t bvh_depth,
                        bool* bvh_in_lds);
 uint32_t bvh_stack_depth();
+size_t trace_lds_bytes_mfma(int threads);
 hipError_t trace_max_blocks_per_cu(bool strict, bool multi, bool accel, size_t lds_bytes, int* out);
-hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, int blocks,
+hipError_t trace_max_blocks_per_cu_mfma(bool multi, size_t lds_bytes, int* out);
+hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, bool mfma, int blocks,
                         hipStream_t stream);
 hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream);

@@ -378,6 +378,9 @@ struct Path {
 };
 
 // Constants of the conservative scan for the segment now in (o, d, a).
+// LEAN: only the `degenerate` verdict (the matrix scan builds its own constants from (o, d, a)
+// and calls the full form just before a tail step, the one place that wants these).
+template <bool LEAN = false>
 __device__ __forceinline__ void prep_segment(Path& P) {
   // The scan evaluates HALF the normalised discriminant, hb'^2 / 2 - c' / 2, as
   // (hb' / sqrt 2)^2 + qh compared with |o|^2 (1 - 2^-17) / 2, where qh = c.o - k'/2 comes
@@ -397,7 +400,7 @@ __device__ __forceinline__ void prep_segment(Path& P) {
   // threshold of -inf makes every filter that uses these constants pass every sphere on.
   const float inf = __builtin_inff();
   P.degenerate = !(P.a > 0.0f) || !(P.a < inf) || !(oo < 1e37f) || !(__builtin_fabsf(P.od) < inf);
-  if (P.degenerate) {
+  if (P.degenerate || LEAN) {
     P.ndx = P.ndy = P.ndz = 0.0f;
     P.od = 0.0f;
     P.thr = -inf;
@@ -540,9 +543,13 @@ __device__ __forceinline__ bool candidate_root(float4 s, V3 o, V3 d, float a, fl
 // against that path's best hit so far (read from its key; a stale value only prunes less) and
 // folds an accepted root into the key with an LDS atomic minimum, which does not depend on the
 // order of arrival.
+// PERM: the records in LDS are (cx, cy, cz, r*r) in the matrix scan's own sphere order, and
+// `index` maps a position in the chunk to the sphere's number in the World (which is what the
+// tie rule and the shading want).
+template <bool PERM = false>
 __device__ __forceinline__ void replay_lists(Path (&P)[R], const float4* sph, const float* sr2,
                                              uint32_t chunk_base, WaveLists& wl, uint32_t lane,
-                                             PhaseClock& clk) {
+                                             PhaseClock& clk, const uint32_t* index = nullptr) {
   const uint32_t n = wl.count;
   if (n == 0) return;   // wave-uniform
 #ifdef RT_DIAG_PHASES
@@ -569,10 +576,10 @@ __device__ __forceinline__ void replay_lists(Path (&P)[R], const float4* sph, co
       const unsigned long long now = wl.keys[slot];
       const float closest = now == kNoHit ? kTMax : __uint_as_float((uint32_t)(now >> 32));
       float4 rec = sph[li];
-      rec.w = sr2[li];
+      if (!PERM) rec.w = sr2[li];
       float root;
       if (candidate_root(rec, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), ro.w, closest, &root))
-        atomicMin(&wl.keys[slot], hit_key(root, chunk_base + li));
+        atomicMin(&wl.keys[slot], hit_key(root, PERM ? index[li] : chunk_base + li));
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -671,6 +678,295 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
         }
       }
     }
+  }
+}
+
+// ---- the scan's filter on the matrix pipe ------------------------------------------------------
+// The sign of the reference's discriminant (src/main.rs:131-135), divided by 2 |d|^2, is a bilinear
+// form between ten numbers of the sphere and ten of the ray.  With n = d / |d|, p = o - (o.n) n
+// (the part of the origin across the ray) and k = |c|^2 - r^2,
+//     disc / (2 |d|^2) = 1/2 (c.n)^2 + c.p - k/2 - |p|^2 / 2
+//   sphere S: cx^2 cy^2 cz^2 cxcy cxcz cycz cx cy cz k
+//   ray    F: nx^2/2 ny^2/2 nz^2/2 nxny nxnz nynz px py pz -1/2         threshold |p|^2 / 2
+// so 16 spheres x 16 rays are one v_mfma_f32_16x16x32_f16: every number is split into two f16
+// halves (hi + lo, 21 bits or more together), a term S F becomes the three products
+// Sh Fh + Sh Fl + Sl Fh, and the 32 slots of the instruction's K hold
+//     0-8 Sh x Fh | 9-17 Sh x Fl | 18-26 Sl x Fh | 27, 28 k in two parts x -1/2 | 29-31: 2^15, 2^5,
+//     2^-5 x the three parts of -threshold (scaled to stay inside f16 for origins out to 46340)
+// A sphere is a candidate for a ray iff the product's entry is not negative.  Centres, radii and
+// ray origins are scaled by a power of two chosen on the host (SceneDev::mfma_scale) so that
+// the bulk of the scene sits below 128, where every feature is a normal f16 number; the few
+// spheres beyond (the ground of the reference's scenes) are listed for every ray instead.
+//
+// Like the vector form, the filter must never drop a sphere that the reference's own arithmetic
+// accepts.  In scaled units, with C = |c|, O = |o|, u = 2^-24: the reference's computed
+// discriminant is >= 0 only if the exact form above is >= -22u (O^2 + C^2) - 11u r^2.  What is
+// computed here differs from the exact form by at most
+//     8.5u C^2 + 20u C O + 23u O^2      n from v_rsq_f32 and two roundings (8u), p and |p|^2 from it
+//   + u C^2                             rounding of the ray's quadratic features
+//   + 28u (C^2 + C O + r^2 / 2)         the halves: host side rounded to nearest (4u), ray side both
+//                                       truncated (16u), lo.lo dropped (8u)
+//   + 16u (C^2 + C O + (r^2 + O^2) / 2) accumulation inside the instruction: four times the worst
+//                                       case measured over 8e5 products with heavy cancellation
+//                                       (3.9u of the sum of magnitudes, tools/ubench/mfma_scan.hip);
+//                                       f16 subnormals are honoured by the instruction (same probe)
+//   + 4u (C^2 + r^2)                    k's two parts
+//   + u O^2                             the threshold's three parts
+//   + 2^-21 max(C^2, C) + 2^-22 (1 + O) subnormal quanta (2^-25) of lo parts times the other side
+// i.e. below 90u C^2 + 64u O^2 + 26u r^2 plus the last line, on top of the reference's 22u / 22u / 11u.  The slack taken off is
+//     sphere side (k, host): 2^-17 C^2 + 2^-18 r^2 + 2^-21 (C^2 + C)          (128u + 8u, 64u)
+//     ray side (threshold):  (2^-17 + 2^-23) O^2 + 1.5 * 2^-22               (128u)
+// which covers the sum of both with room to spare.  A false positive costs one exact replay.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr float kMfmaOriginLimit2 = 2147483648.0f;   // scaled |o|^2 below 2^31: the origin's
+                                                     // features (|p| <= |o| < 46341) and the first
+                                                     // part of the threshold (|o|^2 / 2^16) stay
+                                                     // inside f16
+
+// A ray the matrix filter cannot take (scaled origin beyond the limit) joins the zero and
+// non-finite ones: kept out of the lists, literal loop over all spheres.
+__device__ __forceinline__ void mfma_guard(Path& P, float scale) {
+  const float ox = P.ox * scale, oy = P.oy * scale, oz = P.oz * scale;
+  const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+  if (!(oo < kMfmaOriginLimit2) && !P.degenerate) {
+    P.degenerate = true;
+    P.ndx = P.ndy = P.ndz = 0.0f;
+    P.od = 0.0f;
+    P.thr = -__builtin_inff();
+  }
+}
+
+// The ray's column: 32 f16 in four quarters of 8 slots, built as 16 dwords.  The hi halves are
+// converted ONCE (two at a time, truncating: any rounding serves, the lo half takes what is left)
+// and both copies of a hi half, as well as the value its lo half is measured against, come from
+// those same bits.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bits(float lo_half, float hi_half) {
+  const fp16x2 v = __builtin_amdgcn_cvt_pkrtz(lo_half, hi_half);
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float half_lo(uint32_t w) {
+  return (float)__builtin_bit_cast(h2, w)[0];
+}
+__device__ __forceinline__ float half_hi(uint32_t w) {
+  return (float)__builtin_bit_cast(h2, w)[1];
+}
+__device__ __forceinline__ void mfma_ray_column(const Path& P, bool ok, float scale, h8 (&q)[4]) {
+  uint32_t d[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) d[i] = 0u;
+  d[14] = 0xBC000000u;   // a path that is not scanned: slot 29 = -1, i.e. -2^15 against every row
+  if (ok) {
+    const float s = __builtin_amdgcn_rsqf(P.a);
+    const float nx = P.dx * s, ny = P.dy * s, nz = P.dz * s;
+    const float ox = P.ox * scale, oy = P.oy * scale, oz = P.oz * scale;
+    const float od = __builtin_fmaf(oz, nz, __builtin_fmaf(oy, ny, ox * nx));
+    const float px = __builtin_fmaf(-od, nx, ox), py = __builtin_fmaf(-od, ny, oy),
+                pz = __builtin_fmaf(-od, nz, oz);
+    const float F[9] = {0.5f * (nx * nx), 0.5f * (ny * ny), 0.5f * (nz * nz),
+                        nx * ny, nx * nz, ny * nz, px, py, pz};
+    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float pp = __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px));
+    // (2^-17 + 2^-23) O^2 + 1.5 * 2^-22 off the threshold
+    const float thr = 0.5f * pp - __builtin_fmaf(oo, 7.748603820800781e-06f, 3.5762786865234375e-07f);
+    const uint32_t h01 = pk_bits(F[0], F[1]), h23 = pk_bits(F[2], F[3]), h45 = pk_bits(F[4], F[5]),
+                   h67 = pk_bits(F[6], F[7]), h8x = pk_bits(F[8], 0.0f);
+    // what the hi halves leave (each subtraction is exact)
+    const float l0 = F[0] - half_lo(h01), l1 = F[1] - half_hi(h01), l2 = F[2] - half_lo(h23),
+                l3 = F[3] - half_hi(h23), l4 = F[4] - half_lo(h45), l5 = F[5] - half_hi(h45),
+                l6 = F[6] - half_lo(h67), l7 = F[7] - half_hi(h67), l8 = F[8] - half_lo(h8x);
+    const uint32_t minus_half = 0xB800u;   // -0.5
+    // slots 0-8 Fh | 9-17 Fl | 18-26 Fh | 27, 28 -1/2 | 29-31 the threshold
+    d[0] = h01; d[1] = h23; d[2] = h45; d[3] = h67;
+    d[4] = (h8x & 0xFFFFu) | (pk_bits(l0, 0.0f) << 16);
+    d[5] = pk_bits(l1, l2); d[6] = pk_bits(l3, l4); d[7] = pk_bits(l5, l6); d[8] = pk_bits(l7, l8);
+    d[9] = h01; d[10] = h23; d[11] = h45; d[12] = h67;
+    d[13] = (h8x & 0xFFFFu) | (minus_half << 16);
+    // -threshold in three parts, against 2^15, 2^5 and 2^-5 on the sphere's side: each part takes
+    // ten more bits of what the one before left (the subtractions are exact)
+    const uint32_t t0 = pk_bits(thr * -3.0517578125e-05f, 0.0f) & 0xFFFFu;
+    const float r1 = -thr - half_lo(t0) * 32768.0f;
+    const uint32_t t1 = pk_bits(r1 * 0.03125f, 0.0f) & 0xFFFFu;
+    const float r2 = r1 - half_lo(t1) * 32.0f;
+    const uint32_t t2 = pk_bits(r2 * 32.0f, 0.0f) & 0xFFFFu;
+    d[14] = minus_half | (t0 << 16);
+    d[15] = t1 | (t2 << 16);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint4 w = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+    q[k] = __builtin_bit_cast(h8, w);
+  }
+}
+
+// The columns of the wave's 128 paths as the instruction wants them: ray block j (paths
+// 16 j .. 16 j + 15 of the wave, path slot = lane + 64 r) in b[j], lane l holding slots
+// 8 (l >> 4) .. + 7 of ray l & 15.  Every lane builds the columns of its own two paths and the
+// wave passes them round through `stage` (4 KB of its candidate-list memory, empty just now).
+__device__ __forceinline__ void mfma_prepare(const Path (&P)[R], float scale, h8* stage, uint32_t lane,
+                                             h8 (&b)[8]) {
+  const uint32_t c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    h8 q[4];
+    mfma_ray_column(P[r], P[r].alive && !P[r].degenerate, scale, q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) stage[lane * 4 + k] = q[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) b[4 * r + jj] = stage[(16 * jj + c) * 4 + g];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// What a chunk looks like in LDS for the matrix scan.
+struct MfmaChunk {
+  const h8* rows;          // [4][kMfmaRows]: quarter q of the sphere at position i at rows[q * kMfmaRows + i]
+  const float4* geom;      // [kMfmaChunk] (cx, cy, cz, r*r)
+  const uint32_t* index;   // [kMfmaChunk] sphere number in the World
+};
+
+// Scan one LDS-resident chunk: positions [0, n_rows) have rows, positions [n_rows, cn) are the
+// spheres listed for every ray.  b = mfma_prepare's columns of this step.
+__device__ __forceinline__ void scan_chunk_mfma(Path (&P)[R], const h8 (&b)[8], const MfmaChunk& m,
+                                                uint32_t n_rows, uint32_t cn, WaveLists& wl,
+                                                uint32_t lane, PhaseClock& clk) {
+  const uint32_t c = lane & 15, g = lane >> 4;
+  RT_MARK("scan");
+  // spheres outside the filter's range: one entry per scanned path
+  if (n_rows < cn) {
+    for (uint32_t li = n_rows; li < cn; ++li) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool okl = P[r].alive && !P[r].degenerate;
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(okl);
+        const uint32_t k = (uint32_t)__builtin_popcountll(mm);
+        if (k == 0) continue;
+        if (wl.count + k > L) replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
+        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+        if (okl) wl.list[wl.count + at] = lane | ((li * R + r) << 6);
+        wl.count += k;
+      }
+    }
+  }
+  RT_PRIO_SCAN();
+  const f4v zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  h8 a = m.rows[g * kMfmaRows + c];
+  for (uint32_t blk = 0; blk < n_rows; blk += kMfmaBlock) {
+    const h8 a_now = a;
+    a = m.rows[g * kMfmaRows + blk + kMfmaBlock + c];   // read ahead (the rows are padded by a block)
+    // The wave's 128 paths in two halves of four ray blocks (path slot r = 0, then r = 1): sixteen
+    // results per lane at a time instead of thirty-two keeps the loop inside the register budget.
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f4v acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, b[4 * half + j], zero, 0, 0, 0);
+      // Result i of ray block j is v[4 i + j]: sphere blk + 4 g + i against the path in slot
+      // 64 half + 16 j + c.  A float that is not negative is an integer that is not negative:
+      // the maximum of the 16 as integers says whether this lane has any candidate at all.
+      int v[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[4 * i + j] = __float_as_int(acc[j][i]);
+      int top = v[0];
+#pragma unroll
+      for (int k = 1; k + 1 < 16; k += 2) top = max(max(top, v[k]), v[k + 1]);
+      top = max(top, v[15]);
+#ifdef RT_DIAG_PHASES
+      clk.blocks++;
+#endif
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(top >= 0) != 0, 0)) {
+#ifdef RT_DIAG_PHASES
+        clk.trig_blocks++;
+#endif
+        uint32_t neg = 0;   // bit q = sign of v[q]
+#pragma unroll
+        for (int q = 15; q >= 0; --q) neg = __builtin_amdgcn_alignbit(neg, (uint32_t)v[q], 31);
+        uint32_t cand = ~neg & 0xFFFFu;
+        // an entry = sphere position << 7 | path slot: the lane's base + (i << 7 | j << 4), q = 4 i + j
+        const uint32_t base = ((blk + 4u * g) << 7) | ((uint32_t)half << 6) | c;
+        for (;;) {
+          // every lane's entries go behind those of the lanes below it
+          const uint32_t mine = (uint32_t)__builtin_popcount(cand);
+          uint32_t inc = mine;
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);    // row_shr:1
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);    // row_shr:2
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true);    // row_shr:4
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true);    // row_shr:8
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15
+          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
+          const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+#ifdef RT_DIAG_PHASES
+          clk.trig_pairs += all;
+#endif
+          const uint32_t room = L - wl.count;
+          uint32_t at = wl.count + inc - mine;
+          while (cand != 0 && at < L) {
+            const uint32_t q = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1;
+            wl.list[at] = base + ((q << 5) & 0x180u) + ((q & 3u) << 4);
+            ++at;
+          }
+          if (all <= room) {
+            wl.count += all;
+            break;
+          }
+          // the list is full: replay it, then list what did not fit (still set in `cand`)
+          wl.count = L;
+          RT_STAMP(clk.scan, clk.t0);
+          RT_PRIO_REST();
+          replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
+          RT_STAMP(clk.replay, clk.t0);
+          RT_PRIO_SCAN();
+        }
+      }
+    }
+  }
+  RT_STAMP(clk.scan, clk.t0);
+  RT_PRIO_REST();
+  RT_MARK("replay");
+  replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
+  RT_MARK("replay_end");
+  RT_STAMP(clk.replay, clk.t0);
+}
+
+// Zero, non-finite or out-of-range rays of the matrix scan: World::hit's loop as written
+// (src/main.rs:175-189) over the World in its own order, from global memory.
+__device__ __forceinline__ void literal_world_hit(Path (&P)[R], const SceneDev& sc) {
+  bool odd = false;
+#pragma unroll
+  for (int r = 0; r < R; ++r) odd = odd || (P[r].alive && P[r].degenerate);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (P[r].alive && P[r].degenerate) {
+        const V3 o = mk(P[r].ox, P[r].oy, P[r].oz), d = mk(P[r].dx, P[r].dy, P[r].dz);
+        for (uint32_t k = 0; k < sc.n_spheres; ++k)
+          exact_hit(sc.geom[k], k, o, d, P[r].a, P[r].closest, P[r].best);
+      }
+    }
+  }
+}
+
+// Workgroup-cooperative copy of one chunk of the matrix scan's scene into LDS.
+__device__ __forceinline__ void stage_chunk_mfma(const SceneDev& sc, uint32_t chunk, uint32_t cn,
+                                                 uint4* rows, float4* geom, uint32_t* index) {
+  const uint4* src = sc.mfma_rows + (size_t)chunk * 4 * kMfmaRows;
+  for (uint32_t i = threadIdx.x; i < 4 * kMfmaRows; i += blockDim.x) rows[i] = src[i];
+  for (uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
+    geom[i] = sc.mfma_geom[chunk * kMfmaChunk + i];
+    index[i] = sc.mfma_index[chunk * kMfmaChunk + i];
   }
 }
 
@@ -1015,6 +1311,7 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TracePa
 
 // The sample loop body up to the first segment: jitter (src/cpu/job.rs:50-54) and
 // Camera::get_ray (src/main.rs:70-83, Mat4*Vec4 = ((c0*x + c1*y) + c2*z) + c3*w).
+template <bool LEAN = false>
 __device__ __forceinline__ void start_sample(Path& P, const TraceParams& p) {
   P.rng.g = rt_rng_from_pixel(rt_rng_pixel_a(p.seed_a, P.pixel), rt_rng_pixel_b(p.seed_b, P.pixel),
                               P.sample);
@@ -1036,7 +1333,7 @@ __device__ __forceinline__ void start_sample(Path& P, const TraceParams& p) {
   P.ox = p.origin[0]; P.oy = p.origin[1]; P.oz = p.origin[2];
   P.dx = dir.x; P.dy = dir.y; P.dz = dir.z;
   P.a = dot(dir, dir);
-  prep_segment(P);
+  prep_segment<LEAN>(P);
   P.tr = P.tg = P.tb = 1.0f;
   P.depth = p.max_depth;
   P.alive = true;
@@ -1069,9 +1366,12 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
 #ifndef RT_ACCEL_WAVES
 #define RT_ACCEL_WAVES RT_ACCEL_MIN_WAVES   // waves per SIMD the traversal kernel runs at
 #endif
-template <bool STRICT, bool MULTI, bool ACCEL = false>
-__global__ __launch_bounds__(trace_threads(MULTI, ACCEL), ACCEL ? RT_ACCEL_MIN_WAVES : RT_MIN_WAVES)
+// MFMA (the scan's filter on the matrix pipe, see scan_chunk_mfma): MULTI then means more than
+// kMfmaChunk spheres.
+template <bool STRICT, bool MULTI, bool ACCEL = false, bool MFMA = false>
+__global__ __launch_bounds__(trace_threads(MULTI, ACCEL, MFMA), ACCEL ? RT_ACCEL_MIN_WAVES : RT_MIN_WAVES)
 void trace_kernel(const TraceParams p) {
+  static_assert(!MFMA || (!STRICT && !ACCEL), "the matrix filter replaces the conservative vector scan only");
   constexpr int RP = ACCEL ? 1 : R;   // paths per lane
   extern __shared__ float4 lds[];
   const uint32_t n = p.scene.n_spheres;
@@ -1080,8 +1380,17 @@ void trace_kernel(const TraceParams p) {
   float* sr2 = reinterpret_cast<float*>(lds + cap);        // radius^2 per sphere
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = threadIdx.x / kWave;
+  // MFMA: the chunk's rows, exact records and sphere numbers instead
+  uint4* mrows = reinterpret_cast<uint4*>(lds);
+  float4* mgeom = lds + 4 * kMfmaRows;
+  uint32_t* mindex = reinterpret_cast<uint32_t*>(mgeom + kMfmaChunk);
+  MfmaChunk mc;
+  mc.rows = reinterpret_cast<const h8*>(mrows);
+  mc.geom = mgeom;
+  mc.index = mindex;
   // this wave's candidate lists and hit keys, behind the sphere records
-  unsigned char* wave_lds = reinterpret_cast<unsigned char*>(sr2 + cap) + wave * kWaveLdsBytes;
+  unsigned char* wave_lds = (MFMA ? reinterpret_cast<unsigned char*>(mindex + kMfmaChunk)
+                                  : reinterpret_cast<unsigned char*>(sr2 + cap)) + wave * kWaveLdsBytes;
   WaveLists wl;
   wl.list = reinterpret_cast<uint32_t*>(wave_lds);
   wl.keys = reinterpret_cast<unsigned long long*>(wave_lds + (size_t)L * sizeof(uint32_t));
@@ -1091,7 +1400,8 @@ void trace_kernel(const TraceParams p) {
   wl.redo_from = kNone;
 
   if (!MULTI && !ACCEL) {
-    stage_chunk(p.scene, 0, n, sph, sr2);
+    if (MFMA) stage_chunk_mfma(p.scene, 0, n, mrows, mgeom, mindex);
+    else stage_chunk(p.scene, 0, n, sph, sr2);
     __syncthreads();
   }
   // ACCEL: the LDS holds the traversal stacks instead, one column per thread, and behind them
@@ -1126,7 +1436,7 @@ void trace_kernel(const TraceParams p) {
     P[r].ox = P[r].oy = P[r].oz = 0.0f;
     P[r].dx = P[r].dy = P[r].dz = 0.0f;
     P[r].a = 1.0f;
-    prep_segment(P[r]);
+    prep_segment<MFMA>(P[r]);
     P[r].closest = kTMax;
     P[r].best = kNone;
   }
@@ -1153,7 +1463,8 @@ void trace_kernel(const TraceParams p) {
       const uint32_t item = wave_fetch(need, grab_next, grab_end, exhausted, p, lane);
       if (need && item != kNone) setup_item(P[r], item, p);
       if (!P[r].alive && P[r].has_item && P[r].sample < P[r].sample_end) {
-        start_sample(P[r], p);
+        start_sample<MFMA>(P[r], p);
+        if (MFMA) mfma_guard(P[r], p.scene.mfma_scale);
         n_samples++;
       }
     }
@@ -1197,6 +1508,32 @@ void trace_kernel(const TraceParams p) {
       if (p.bvh_in_lds) bvh_hit<true>(P[0], p.scene, bvh_src, bvh_stack, bvh_interior, bvh_tests);
       else bvh_hit<false>(P[0], p.scene, bvh_src, bvh_stack, bvh_interior, bvh_tests);
       RT_STAMP(clk.scan, clk.t0);   // the traversal is this mode's "scan"
+    } else if constexpr (MFMA) {
+      h8 cols[8];
+      if (!tail) mfma_prepare(P, p.scene.mfma_scale, reinterpret_cast<h8*>(wl.list), lane, cols);
+      const uint32_t n_in = n - p.scene.mfma_always;   // positions with rows; the rest are listed
+      for (uint32_t base = 0, chunk = 0; base < n; base += kMfmaChunk, ++chunk) {
+        const uint32_t cn = n - base < kMfmaChunk ? n - base : kMfmaChunk;
+        if (MULTI) {
+          __syncthreads();   // every wave is done with the previous chunk
+          stage_chunk_mfma(p.scene, chunk, cn, mrows, mgeom, mindex);
+          __syncthreads();
+        }
+        const uint32_t n_rows = base >= n_in ? 0u : (n_in - base < cn ? n_in - base : cn);
+        if (!tail) scan_chunk_mfma(P, cols, mc, n_rows, cn, wl, lane, clk);
+      }
+      if (tail) {
+        // the tail step's filter is the vector form: its constants are formed here, on demand
+        // (no tail step is taken while a zero, non-finite or out-of-range ray is alive)
+#pragma unroll
+        for (int r = 0; r < RP; ++r)
+          if (P[r].alive) prep_segment<false>(P[r]);
+        tail_hit<false, false>(P, p.scene, sph, sr2, reinterpret_cast<float*>(wl.list), lane);
+#pragma unroll
+        for (int r = 0; r < RP; ++r) prep_segment<true>(P[r]);
+      } else {
+        literal_world_hit(P, p.scene);
+      }
     } else if constexpr (MULTI) {
       for (uint32_t base = 0; base < n; base += kChunkSpheres) {
         const uint32_t cn = n - base < kChunkSpheres ? n - base : kChunkSpheres;
@@ -1240,7 +1577,8 @@ void trace_kernel(const TraceParams p) {
             P[r].ox = b.point.x; P[r].oy = b.point.y; P[r].oz = b.point.z;
             P[r].dx = b.dir.x; P[r].dy = b.dir.y; P[r].dz = b.dir.z;
             P[r].a = dot(b.dir, b.dir);
-            prep_segment(P[r]);
+            prep_segment<MFMA>(P[r]);
+            if (MFMA) mfma_guard(P[r], p.scene.mfma_scale);
             P[r].depth--;
             ended = P[r].depth == 0;   // `if depth <= 0 { return black }`, src/main.rs:192-194
           }
@@ -1372,7 +1710,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveParams p) {
 // scan / replay / shade code as the main kernel.  Path slot 0 of each lane carries the ray.
 // bvh_hit strides its LDS stack by kThreadsAccel; this kernel runs it in kThreads-wide workgroups.
 static_assert(kThreads == kThreadsAccel, "hook_kernel's traversal stack assumes equal workgroup sizes");
-template <bool STRICT>
+template <bool STRICT, bool MFMA = false>
 __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   extern __shared__ float4 lds[];
   float4* sph = lds;
@@ -1380,8 +1718,12 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   float* sr2 = reinterpret_cast<float*>(lds + cap);
   const uint32_t lane = threadIdx.x & (kWave - 1);
   const uint32_t wave = threadIdx.x / kWave;
+  uint4* mrows = reinterpret_cast<uint4*>(lds);
+  float4* mgeom = lds + 4 * kMfmaRows;
+  uint32_t* mindex = reinterpret_cast<uint32_t*>(mgeom + kMfmaChunk);
   // this wave's candidate lists and hit keys, behind the sphere records
-  unsigned char* wave_lds = reinterpret_cast<unsigned char*>(sr2 + cap) + wave * kWaveLdsBytes;
+  unsigned char* wave_lds = (MFMA ? reinterpret_cast<unsigned char*>(mindex + kMfmaChunk)
+                                  : reinterpret_cast<unsigned char*>(sr2 + cap)) + wave * kWaveLdsBytes;
   WaveLists wl;
   wl.list = reinterpret_cast<uint32_t*>(wave_lds);
   wl.keys = reinterpret_cast<unsigned long long*>(wave_lds + (size_t)L * sizeof(uint32_t));
@@ -1409,10 +1751,29 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     P[0].dx = in.dx; P[0].dy = in.dy; P[0].dz = in.dz;
     P[0].a = dot(mk(in.dx, in.dy, in.dz), mk(in.dx, in.dy, in.dz));
     prep_segment(P[0]);
+    if (MFMA) mfma_guard(P[0], p.scene.mfma_scale);
     P[0].alive = true;
   }
   const uint32_t n = p.scene.n_spheres;
-  if (p.accel) {
+  if constexpr (MFMA) {
+    MfmaChunk mc;
+    mc.rows = reinterpret_cast<const h8*>(mrows);
+    mc.geom = mgeom;
+    mc.index = mindex;
+    h8 cols[8];
+    mfma_prepare(P, p.scene.mfma_scale, reinterpret_cast<h8*>(wl.list), lane, cols);
+    const uint32_t n_in = n - p.scene.mfma_always;
+    PhaseClock clk = {};
+    for (uint32_t base = 0, chunk = 0; base < n; base += kMfmaChunk, ++chunk) {
+      const uint32_t cn = n - base < kMfmaChunk ? n - base : kMfmaChunk;
+      __syncthreads();
+      stage_chunk_mfma(p.scene, chunk, cn, mrows, mgeom, mindex);
+      __syncthreads();
+      const uint32_t n_rows = base >= n_in ? 0u : (n_in - base < cn ? n_in - base : cn);
+      scan_chunk_mfma(P, cols, mc, n_rows, cn, wl, lane, clk);
+    }
+    literal_world_hit(P, p.scene);
+  } else if (p.accel) {
     BvhSource bvh_src;
     bvh_src.nodes = reinterpret_cast<const float4*>(p.scene.bvh);
     bvh_src.leaf_geom = p.scene.leaf_geom;
@@ -1493,6 +1854,15 @@ size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint3
          queue_bytes(trace_threads(n_spheres > kChunkSpheres, false));
 }
 
+size_t trace_lds_bytes_mfma(int threads) {
+  return (size_t)4 * kMfmaRows * sizeof(uint4) + (size_t)kMfmaChunk * (sizeof(float4) + sizeof(uint32_t)) +
+         queue_bytes(threads);
+}
+static_assert((size_t)4 * kMfmaRows * sizeof(uint4) + (size_t)kMfmaChunk * (sizeof(float4) + sizeof(uint32_t)) +
+                      queue_bytes(kThreadsMfma) + 256 <= 160 * 1024,
+              "the matrix scan's workgroup must fit into a CU's LDS");
+static_assert(kWaveLdsBytes >= 64 * 4 * sizeof(uint4), "mfma_prepare stages 64 columns in the wave's list memory");
+
 uint32_t bvh_stack_depth() { return kBvhStack; }
 
 template <bool STRICT, bool MULTI>
@@ -1509,8 +1879,33 @@ hipError_t trace_max_blocks_per_cu(bool strict, bool multi, bool accel, size_t l
   return multi ? occupancy<false, true>(lds, out) : occupancy<false, false>(lds, out);
 }
 
-hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, int blocks,
+hipError_t trace_max_blocks_per_cu_mfma(bool multi, size_t lds, int* out) {
+  // 155 KB of dynamic LDS: above the default limit of a kernel
+  hipError_t e;
+  if (multi) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_kernel<false, true, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, trace_kernel<false, true, false, true>,
+                                                        kThreadsMfma, lds);
+  }
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_kernel<false, false, false, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, trace_kernel<false, false, false, true>,
+                                                      kThreadsMfma, lds);
+}
+
+hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, bool mfma, int blocks,
                         hipStream_t stream) {
+  if (mfma) {
+    const bool many = p.scene.n_spheres > kMfmaChunk;
+    const size_t lds = trace_lds_bytes_mfma(kThreadsMfma);
+    const dim3 grid(blocks), block(kThreadsMfma);
+    if (many) hipLaunchKernelGGL((trace_kernel<false, true, false, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((trace_kernel<false, false, false, true>), grid, block, lds, stream, p);
+    return hipGetLastError();
+  }
   const bool multi = p.scene.n_spheres > kChunkSpheres;
   const size_t lds = trace_lds_bytes(p.scene.n_spheres, accel, p.scene.bvh_info.n_nodes,
                                      p.bvh_stack, nullptr);
@@ -1549,7 +1944,13 @@ hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream) {
   const size_t lds = (size_t)lds_capacity(kChunkSpheres) * (sizeof(float4) + sizeof(float)) +
                      queue_bytes(kThreads);
   const dim3 grid((p.n_rays + kThreads - 1) / kThreads), block(kThreads);
-  if (strict) hipLaunchKernelGGL((hook_kernel<true>), grid, block, lds, stream, p);
+  if (p.mfma) {
+    const size_t mlds = trace_lds_bytes_mfma(kThreads);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hook_kernel<false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((hook_kernel<false, true>), grid, block, mlds, stream, p);
+  } else if (strict) hipLaunchKernelGGL((hook_kernel<true>), grid, block, lds, stream, p);
   else hipLaunchKernelGGL((hook_kernel<false>), grid, block, lds, stream, p);
   return hipGetLastError();
 }
