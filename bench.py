@@ -12,9 +12,16 @@ ranks in blocks of 8, each rank renders its blocks and one RCCL gather brings th
 to rank 0 (strong scaling: the frame is fixed).  Rank 0 prints ONE JSON line.
 
   value      whole-job Msamples/s = W*H*spp*steps / max-over-ranks wall time
-  roofline   dominant kernel (trace_kernel) against the FP32 vector-ALU peak: achieved =
-             17 flop * n_spheres * rays / kernel time, with rays counted by the kernel itself
-             and kernel time from HIP events on the launch stream (rank 0's launches)
+  roofline   dominant kernel (trace_kernel).  Its ray/sphere filter runs on the matrix pipe
+             (v_mfma_f32_16x16x32_f16, 32 slots = 64 flop per test as issued), so the bound is
+             the dense f16 MFMA peak: achieved = 64 flop * n_spheres * rays / kernel time, with
+             rays counted by the kernel itself and kernel time from HIP events on the launch
+             stream (rank 0's launches).  `fp32_form` prices the same launch the way the
+             reference states the test (17 flop, src/main.rs:131-135) against the FP32
+             vector-ALU peak, the figure the metric names
+  valu_scan  the same frame with the filter kept on the vector ALU (RT_FLAG_SCAN_VALU: seven
+             fused f32 instructions and a compare per test), with its own roofline against the
+             FP32 vector-ALU peak (N = 1 only)
   cpu_baseline  the CPU restatement of the reference's multithreaded tile renderer
              (oracle/, kind "port") timed on this host's cores on a reduced sample of the
              same workload (N = 1 only)
@@ -30,8 +37,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz (MI355X)
 FLOP_PER_TEST = 17              # one ray/sphere discriminant, src/main.rs:131-135 with a hoisted
-FLOP_PER_TEST_EXECUTED = 14     # what the kernel's scan issues per test: 7 fused multiply-adds
+FLOP_PER_TEST_EXECUTED = 14     # what the vector scan issues per test: 7 fused multiply-adds
                                 # (and one compare, not counted)
+PEAK_F16_MFMA_TFLOPS = 2500.0   # dense f16 matrix peak: 1024 SIMDs x 16x16x32x2 flop / 16 clk x 2.4 GHz
+FLOP_PER_TEST_MFMA = 64         # one (sphere, ray) entry of a 16x16x32 product: 32 slots x 2 flop
 
 CONFIGS = {
     # the configuration the headline metric is quoted on
@@ -177,6 +186,31 @@ def profiled_traffic(config, kernel):
             "%s (rocprofv3 --pmc, bytes per launch of an earlier run of this command%s)" % (rel, commit))
 
 
+def valu_roofline(achieved, traffic, traffic_source, kernel_name, kernel_ms, kernel_ms_source, st):
+    """Roofline of a launch whose filter ran on the vector ALU, against the FP32 VALU peak."""
+    return {
+        "bound": "valu_fp32",
+        "achieved": round(achieved, 3),
+        "peak": PEAK_FP32_VALU_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+        "traffic": traffic,
+        "traffic_source": traffic_source,
+        "kernel": kernel_name,
+        "kernel_ms": round(kernel_ms, 3),
+        "kernel_ms_source": kernel_ms_source,
+        "rays_per_launch": int(st.rays),
+        "rays_per_sample": round(st.rays / max(st.samples, 1), 4),
+        "flop_per_ray_sphere_test": FLOP_PER_TEST,
+        "frac_executed": round(achieved / PEAK_FP32_VALU_TFLOPS
+                               * FLOP_PER_TEST_EXECUTED / FLOP_PER_TEST, 4),
+        "frac_executed_note": "the same launch priced at the 14 flop (7 FMA, plus a "
+                              "compare that is not counted) per test the scan actually "
+                              "issues instead of the reference's 17",
+        "rank": 0,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -304,8 +338,13 @@ def main():
     n_spheres = len(scene_host.spheres)
     flop = FLOP_PER_TEST * n_spheres * st.rays
     achieved = flop / (kernel_ms * 1e-3) * 1e-12 if kernel_ms > 0 else 0.0
+    matrix = st.threads_per_workgroup == 1024      # the launch ran the matrix filter
+    achieved_mfma = achieved * FLOP_PER_TEST_MFMA / FLOP_PER_TEST
 
-    kernel_name = "rt::trace_kernel<false,%s,false>" % ("true" if n_spheres > 1200 else "false")
+    if matrix:
+        kernel_name = "rt::trace_kernel<false,%s,false,true>" % ("true" if n_spheres > 512 else "false")
+    else:
+        kernel_name = "rt::trace_kernel<false,%s,false,false>" % ("true" if n_spheres > 1200 else "false")
     if rank == 0:
         traffic, traffic_source = (profiled_traffic(args.config, kernel_name) if world == 1
                                    else (None, "not reported for N > 1"))
@@ -335,12 +374,13 @@ def main():
                 "sharding": "rows in blocks of %d dealt round-robin over %d rank(s)%s"
                             % (plan.block_rows, world, ", RCCL gather to rank 0" if world > 1 else ""),
             },
-            "roofline": {
-                "bound": "valu_fp32",
-                "achieved": round(achieved, 3),
-                "peak": PEAK_FP32_VALU_TFLOPS,
+            "roofline": valu_roofline(achieved, traffic, traffic_source, kernel_name, kernel_ms,
+                                      kernel_ms_source, st) if not matrix else {
+                "bound": "mfma",
+                "achieved": round(achieved_mfma, 3),
+                "peak": PEAK_F16_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+                "frac": round(achieved_mfma / PEAK_F16_MFMA_TFLOPS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_source,
                 "kernel": kernel_name,
@@ -348,12 +388,21 @@ def main():
                 "kernel_ms_source": kernel_ms_source,
                 "rays_per_launch": int(st.rays),
                 "rays_per_sample": round(st.rays / max(st.samples, 1), 4),
-                "flop_per_ray_sphere_test": FLOP_PER_TEST,
-                "frac_executed": round(achieved / PEAK_FP32_VALU_TFLOPS
-                                       * FLOP_PER_TEST_EXECUTED / FLOP_PER_TEST, 4),
-                "frac_executed_note": "the same launch priced at the 14 flop (7 FMA, plus a "
-                                      "compare that is not counted) per test the scan actually "
-                                      "issues instead of the reference's 17",
+                "flop_per_ray_sphere_test": FLOP_PER_TEST_MFMA,
+                "flop_note": "one (sphere, ray) entry of v_mfma_f32_16x16x32_f16: 32 slots (ten "
+                             "terms of the discriminant's bilinear form, three split-f16 products "
+                             "each, and the threshold) x 2 flop; frac is also the share of time "
+                             "the matrix pipe is busy at the nominal clock",
+                "fp32_form": {
+                    "flop_per_ray_sphere_test": FLOP_PER_TEST,
+                    "achieved": round(achieved, 3),
+                    "peak": PEAK_FP32_VALU_TFLOPS,
+                    "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4),
+                    "note": "the same launch priced as the reference states the test (17 flop) "
+                            "against the FP32 vector-ALU peak; it can pass 1 because the filter "
+                            "no longer runs on the vector ALU (see valu_scan for the kernel that does)",
+                },
                 "rank": 0,
             },
         }
@@ -362,6 +411,36 @@ def main():
         if world == 1:
             line["drop_in"] = drop_in_leg(hip, scene_host, camera, W, H, spp, depth, args.seed,
                                           args.steps, kernel_ms, torch.cuda.device_count())
+        if world == 1 and matrix:
+            # The same frame with the filter on the vector ALU (the kernel the FP32 VALU roofline
+            # describes), timed by HIP events around each launch.
+            from ray_tracing_amd import abi
+            vframe = hip.make_frame(camera.m, W, H, spp, depth, args.seed, flags=abi.RT_FLAG_SCAN_VALU)
+            vout = torch.zeros_like(fb)
+            raw = torch.cuda.current_stream().cuda_stream
+            hip.render_rows_device_async(scene, vframe, 0, H, True, vout.data_ptr(), raw)
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(args.steps):
+                hip.render_rows_device_async(scene, vframe, 0, H, True, vout.data_ptr(), raw)
+            torch.cuda.synchronize()
+            tv = (time.perf_counter() - tv) / args.steps
+            v_ms = hip.get_launch_ms(min(args.steps, 64))
+            v_st = hip.get_stats()
+            v_kernel_ms = float(v_ms.mean()) if len(v_ms) else float("nan")
+            v_name = "rt::trace_kernel<false,%s,false,false>" % ("true" if n_spheres > 1200 else "false")
+            v_traffic, v_source = profiled_traffic(args.config, v_name)
+            v_achieved = FLOP_PER_TEST * n_spheres * v_st.rays / (v_kernel_ms * 1e-3) * 1e-12
+            line["valu_scan"] = {
+                "value": round(samples_per_step / tv * 1e-6, 2),
+                "unit": "Msamples/s",
+                "ms_per_step": round(tv * 1e3, 3),
+                "same_pixels_as_headline": bool(torch.equal(vout.view(torch.int32), fb.view(torch.int32))),
+                "roofline": valu_roofline(v_achieved, v_traffic, v_source, v_name, v_kernel_ms,
+                                          "HIP events around each launch on its stream", v_st),
+                "note": "RT_FLAG_SCAN_VALU: the ray/sphere filter as seven fused f32 instructions and "
+                        "a compare per test on the vector ALU, everything else the same kernel code",
+            }
         if world == 1:
             # The opt-in mode that walks a bounding-volume hierarchy instead of testing every
             # sphere (RT_FLAG_ACCEL): same pixels, bit for bit, but not the brute-force work the

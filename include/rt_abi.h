@@ -305,6 +305,22 @@ int rt_get_launch_ms(uint32_t n_last, float* out_ms);
  * shares; its stamps slow the kernel down).  No counterpart in the reference. */
 int rt_get_phase_cycles(uint64_t* out16);
 
+/* How World::hit's scan will filter this scene's spheres.  No counterpart in the reference
+ * (its World::hit, src/main.rs:175-189, tests every sphere); exists so that a host, a test or a
+ * benchmark can tell which of the two filters its frames run on. */
+typedef struct rt_scan_info {
+  uint32_t matrix_filter;      /* 1: the filter runs on the matrix pipe unless a request sets
+                                  RT_FLAG_SCAN_VALU, RT_FLAG_STRICT_FP or RT_FLAG_ACCEL (or its camera
+                                  sits beyond the filter's range); 0: this scene keeps to the
+                                  vector ALU (no sphere, or non-finite sizes) */
+  uint32_t listed_spheres;     /* spheres outside the filter's f16 range (a factor 4 above the rest
+                                  in max(|centre|, radius), at most 8): listed for every ray */
+  float scale;                 /* power of two applied to centres, radii and ray origins */
+  float origin_limit;          /* rays whose origin is farther than this from the World's origin
+                                  take the literal loop over all spheres */
+} rt_scan_info;
+int rt_scene_scan_info(const rt_scene* scene, rt_scan_info* out);
+
 /* ---- test hook --------------------------------------------------------------------------- */
 
 /* One World::hit + one scatter decision per input ray (reference src/main.rs:175-189 and the

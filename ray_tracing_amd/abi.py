@@ -89,6 +89,15 @@ class RtStats(C.Structure):
     ]
 
 
+class RtScanInfo(C.Structure):
+    _fields_ = [
+        ("matrix_filter", C.c_uint32),
+        ("listed_spheres", C.c_uint32),
+        ("scale", C.c_float),
+        ("origin_limit", C.c_float),
+    ]
+
+
 def camera_from_arrays(view_inv, proj_inv):
     cam = RtCamera()
     v = np.asarray(view_inv, dtype=np.float32).reshape(16)

@@ -1467,6 +1467,15 @@ int rt_compose(const rt_tile* tiles, uint32_t n_tiles, const float* tile_sums, u
   return RT_OK;
 }
 
+int rt_scene_scan_info(const rt_scene* scene, rt_scan_info* out) {
+  if (!scene || !out) return fail(RT_ERR_INVALID_ARGUMENT, "NULL scene or out");
+  out->matrix_filter = scene->dev.mfma_ok;
+  out->listed_spheres = scene->dev.mfma_always;
+  out->scale = scene->dev.mfma_ok ? scene->dev.mfma_scale : 1.0f;
+  out->origin_limit = scene->dev.mfma_ok ? 46340.0f / scene->dev.mfma_scale : 0.0f;   // sqrt(2^31)
+  return RT_OK;
+}
+
 int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays, uint32_t seed,
                   uint32_t flags, rt_ray_out* out) {
   ApiScope scope;

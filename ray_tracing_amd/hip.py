@@ -25,6 +25,7 @@ EXPORTS = (
     "rt_render_device_async", "rt_render_rows_device_async", "rt_render_rows_device_noalloc",
     "rt_accumulate_device_async", "rt_resolve_device_async",
     "rt_synchronize", "rt_get_stats", "rt_get_launch_ms", "rt_get_phase_cycles", "rt_trace_rays",
+    "rt_scene_scan_info",
 )
 
 
@@ -92,6 +93,7 @@ def lib():
     L.rt_get_launch_ms.restype = i
     L.rt_get_phase_cycles.argtypes = [vp]
     L.rt_trace_rays.argtypes = [vp, vp, u32, u32, u32, vp]
+    L.rt_scene_scan_info.argtypes = [vp, C.POINTER(abi.RtScanInfo)]
     _lib = L
     return L
 
@@ -119,6 +121,12 @@ class Scene:
         check(lib().rt_scene_create(abi.ptr(self.spheres), len(self.spheres),
                                     abi.ptr(self.materials), len(self.materials), C.byref(h)))
         self.handle = h
+
+    def scan_info(self):
+        """Which filter World::hit's scan runs on for this scene (rt_scene_scan_info)."""
+        info = abi.RtScanInfo()
+        check(lib().rt_scene_scan_info(self.handle, C.byref(info)))
+        return info
 
     def close(self):
         if self.handle is not None:
