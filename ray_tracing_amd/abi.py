@@ -3,7 +3,7 @@
 These carry the reference's scene types across the C ABI: Sphere (reference src/main.rs:119-125),
 Material (src/main.rs:108-117), Camera (src/main.rs:51-55), TileJob (src/cpu/job.rs:6-13) and
 Dispatch (src/cpu/mod.rs:19-30).  Layouts must match the header byte for byte;
-tests/test_abi_layout.py checks the sizes against a C program compiled from the header.
+tests/test_abi_library.py checks the sizes against a C program compiled from the header.
 """
 import ctypes as C
 

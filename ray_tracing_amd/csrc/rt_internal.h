@@ -58,6 +58,11 @@ constexpr uint32_t kLaneSlots = 256u * 2u * kThreads * kRaysPerLane;   // paths 
 #ifndef RT_TAIL_PATHS
 #define RT_TAIL_PATHS 16
 #endif
+#ifndef RT_TAIL_PATHS_MFMA
+#define RT_TAIL_PATHS_MFMA 4
+#endif
+constexpr uint32_t kTailPathsMfma = RT_TAIL_PATHS_MFMA;   // the same for the matrix scan, whose
+                                                          // step costs the same for 128 paths as for 5
 constexpr uint32_t kTailPaths = RT_TAIL_PATHS;  // a wave with no work left and at most this many
                                                 // live paths traces them with the spheres spread
                                                 // across its lanes

@@ -77,8 +77,15 @@ namespace {
 // have an instruction ready.  Letting those chains go first shortens them and leaves the scan
 // the same issue slots (-0.8 % kernel time on the benchmark frame, -1.1 % on the glass scene;
 // the opposite assignment costs +2.8 %).
+#ifndef RT_PRIO_REST_LEVEL
+#define RT_PRIO_REST_LEVEL 3
+#endif
+#ifndef RT_PRIO_MFMA_LEVEL
+#define RT_PRIO_MFMA_LEVEL 0
+#endif
 #define RT_PRIO_SCAN() __builtin_amdgcn_s_setprio(0)
-#define RT_PRIO_REST() __builtin_amdgcn_s_setprio(3)
+#define RT_PRIO_REST() __builtin_amdgcn_s_setprio(RT_PRIO_REST_LEVEL)
+#define RT_PRIO_MFMA() __builtin_amdgcn_s_setprio(RT_PRIO_MFMA_LEVEL)
 
 struct PhaseClock {
   unsigned long long t0, refill, scan, replay, shade, steps;
@@ -857,7 +864,10 @@ __device__ __forceinline__ void scan_chunk_mfma(Path (&P)[R], const h8 (&b)[8], 
       }
     }
   }
-  RT_PRIO_SCAN();
+  RT_PRIO_MFMA();
+  bool scanned[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) scanned[r] = __builtin_amdgcn_ballot_w64(P[r].alive && !P[r].degenerate) != 0;
   const f4v zero = {0.0f, 0.0f, 0.0f, 0.0f};
   h8 a = m.rows[g * kMfmaRows + c];
   for (uint32_t blk = 0; blk < n_rows; blk += kMfmaBlock) {
@@ -867,6 +877,7 @@ __device__ __forceinline__ void scan_chunk_mfma(Path (&P)[R], const h8 (&b)[8], 
     // results per lane at a time instead of thirty-two keeps the loop inside the register budget.
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+      if (!scanned[half]) continue;   // wave-uniform: no path of this half is being scanned
       f4v acc[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -928,7 +939,7 @@ __device__ __forceinline__ void scan_chunk_mfma(Path (&P)[R], const h8 (&b)[8], 
           RT_PRIO_REST();
           replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
           RT_STAMP(clk.replay, clk.t0);
-          RT_PRIO_SCAN();
+          RT_PRIO_MFMA();
         }
       }
     }
@@ -960,13 +971,18 @@ __device__ __forceinline__ void literal_world_hit(Path (&P)[R], const SceneDev& 
 }
 
 // Workgroup-cooperative copy of one chunk of the matrix scan's scene into LDS.
+// `khalf` (the vector filter's -k'/2 per sphere, for tail steps) is filled when the whole scene is
+// one chunk; a scene of several chunks takes its tail steps from global memory.
 __device__ __forceinline__ void stage_chunk_mfma(const SceneDev& sc, uint32_t chunk, uint32_t cn,
-                                                 uint4* rows, float4* geom, uint32_t* index) {
+                                                 uint4* rows, float4* geom, uint32_t* index,
+                                                 float* khalf = nullptr) {
   const uint4* src = sc.mfma_rows + (size_t)chunk * 4 * kMfmaRows;
   for (uint32_t i = threadIdx.x; i < 4 * kMfmaRows; i += blockDim.x) rows[i] = src[i];
   for (uint32_t i = threadIdx.x; i < cn; i += blockDim.x) {
     geom[i] = sc.mfma_geom[chunk * kMfmaChunk + i];
-    index[i] = sc.mfma_index[chunk * kMfmaChunk + i];
+    const uint32_t world = sc.mfma_index[chunk * kMfmaChunk + i];
+    index[i] = world;
+    if (khalf) khalf[i] = sc.trig[world].w;
   }
 }
 
@@ -988,9 +1004,13 @@ static_assert((kTailFloats + 2) * kWave * sizeof(float) <= kWaveLdsBytes,
               "the tail exchange must fit the wave's candidate lists");
 static_assert(kTailPaths <= (uint32_t)kWave, "one group of lanes per live path");
 
-template <bool STRICT, bool IN_LDS>
+// PERM (with IN_LDS): the LDS holds the matrix scan's copy instead, spheres in its own order:
+// `sph` = (cx, cy, cz, r*r), `sr2` = -k'/2, `index` = the sphere's number in the World (what the
+// tie rule compares).
+template <bool STRICT, bool IN_LDS, bool PERM = false>
 __device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, const float4* sph,
-                                         const float* sr2, float* xch, uint32_t lane) {
+                                         const float* sr2, float* xch, uint32_t lane,
+                                         const uint32_t* index = nullptr) {
   // pack the live paths: slot numbers 0..n-1, path slot 0 of every lane first
   uint32_t slot[R];
   uint32_t n = 0;
@@ -1031,12 +1051,13 @@ __device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, const
       const float4 s = IN_LDS ? sph[i] : sc.trig[i];
       if (!STRICT) {
         // the same filter, with the same guarantee, as test_block's conservative form
+        const float kh = PERM ? sr2[i] : s.w;
         const float hb = __builtin_fmaf(s.z, ndz, __builtin_fmaf(s.y, ndy, __builtin_fmaf(s.x, ndx, od)));
-        const float qh = __builtin_fmaf(s.z, oz, __builtin_fmaf(s.y, oy, __builtin_fmaf(s.x, ox, s.w)));
+        const float qh = __builtin_fmaf(s.z, oz, __builtin_fmaf(s.y, oy, __builtin_fmaf(s.x, ox, kh)));
         if (__builtin_fmaf(hb, hb, qh) < thr) continue;
       }
-      const float4 geo = IN_LDS ? make_float4(s.x, s.y, s.z, sr2[i]) : sc.geom[i];
-      candidate_hit(geo, i, mk(ox, oy, oz), mk(dx, dy, dz), a, rb, c, b);
+      const float4 geo = PERM ? s : IN_LDS ? make_float4(s.x, s.y, s.z, sr2[i]) : sc.geom[i];
+      candidate_hit(geo, PERM ? index[i] : i, mk(ox, oy, oz), mk(dx, dy, dz), a, rb, c, b);
     }
   }
   // minimum over the lanes of each group (all 64 lanes take part; idle ones carry "no hit")
@@ -1384,12 +1405,13 @@ void trace_kernel(const TraceParams p) {
   uint4* mrows = reinterpret_cast<uint4*>(lds);
   float4* mgeom = lds + 4 * kMfmaRows;
   uint32_t* mindex = reinterpret_cast<uint32_t*>(mgeom + kMfmaChunk);
+  float* mkhalf = reinterpret_cast<float*>(mindex + kMfmaChunk);
   MfmaChunk mc;
   mc.rows = reinterpret_cast<const h8*>(mrows);
   mc.geom = mgeom;
   mc.index = mindex;
   // this wave's candidate lists and hit keys, behind the sphere records
-  unsigned char* wave_lds = (MFMA ? reinterpret_cast<unsigned char*>(mindex + kMfmaChunk)
+  unsigned char* wave_lds = (MFMA ? reinterpret_cast<unsigned char*>(mkhalf + kMfmaChunk)
                                   : reinterpret_cast<unsigned char*>(sr2 + cap)) + wave * kWaveLdsBytes;
   WaveLists wl;
   wl.list = reinterpret_cast<uint32_t*>(wave_lds);
@@ -1400,7 +1422,7 @@ void trace_kernel(const TraceParams p) {
   wl.redo_from = kNone;
 
   if (!MULTI && !ACCEL) {
-    if (MFMA) stage_chunk_mfma(p.scene, 0, n, mrows, mgeom, mindex);
+    if (MFMA) stage_chunk_mfma(p.scene, 0, n, mrows, mgeom, mindex, mkhalf);
     else stage_chunk(p.scene, 0, n, sph, sr2);
     __syncthreads();
   }
@@ -1502,7 +1524,7 @@ void trace_kernel(const TraceParams p) {
         live += __builtin_popcountll(__builtin_amdgcn_ballot_w64(P[r].alive));
         odd = odd || (P[r].alive && P[r].degenerate);
       }
-      tail = live <= kTailPaths && __builtin_amdgcn_ballot_w64(odd) == 0;
+      tail = live <= (MFMA ? kTailPathsMfma : kTailPaths) && __builtin_amdgcn_ballot_w64(odd) == 0;
     }
     if constexpr (ACCEL) {
       if (p.bvh_in_lds) bvh_hit<true>(P[0], p.scene, bvh_src, bvh_stack, bvh_interior, bvh_tests);
@@ -1528,7 +1550,8 @@ void trace_kernel(const TraceParams p) {
 #pragma unroll
         for (int r = 0; r < RP; ++r)
           if (P[r].alive) prep_segment<false>(P[r]);
-        tail_hit<false, false>(P, p.scene, sph, sr2, reinterpret_cast<float*>(wl.list), lane);
+        if (MULTI) tail_hit<false, false>(P, p.scene, sph, sr2, reinterpret_cast<float*>(wl.list), lane);
+        else tail_hit<false, true, true>(P, p.scene, mgeom, mkhalf, reinterpret_cast<float*>(wl.list), lane, mindex);
 #pragma unroll
         for (int r = 0; r < RP; ++r) prep_segment<true>(P[r]);
       } else {
@@ -1722,7 +1745,7 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   float4* mgeom = lds + 4 * kMfmaRows;
   uint32_t* mindex = reinterpret_cast<uint32_t*>(mgeom + kMfmaChunk);
   // this wave's candidate lists and hit keys, behind the sphere records
-  unsigned char* wave_lds = (MFMA ? reinterpret_cast<unsigned char*>(mindex + kMfmaChunk)
+  unsigned char* wave_lds = (MFMA ? reinterpret_cast<unsigned char*>(mindex + 2 * kMfmaChunk)
                                   : reinterpret_cast<unsigned char*>(sr2 + cap)) + wave * kWaveLdsBytes;
   WaveLists wl;
   wl.list = reinterpret_cast<uint32_t*>(wave_lds);
@@ -1855,10 +1878,11 @@ size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint3
 }
 
 size_t trace_lds_bytes_mfma(int threads) {
-  return (size_t)4 * kMfmaRows * sizeof(uint4) + (size_t)kMfmaChunk * (sizeof(float4) + sizeof(uint32_t)) +
-         queue_bytes(threads);
+  return (size_t)4 * kMfmaRows * sizeof(uint4) +
+         (size_t)kMfmaChunk * (sizeof(float4) + sizeof(uint32_t) + sizeof(float)) + queue_bytes(threads);
 }
-static_assert((size_t)4 * kMfmaRows * sizeof(uint4) + (size_t)kMfmaChunk * (sizeof(float4) + sizeof(uint32_t)) +
+static_assert((size_t)4 * kMfmaRows * sizeof(uint4) +
+                      (size_t)kMfmaChunk * (sizeof(float4) + sizeof(uint32_t) + sizeof(float)) +
                       queue_bytes(kThreadsMfma) + 256 <= 160 * 1024,
               "the matrix scan's workgroup must fit into a CU's LDS");
 static_assert(kWaveLdsBytes >= 64 * 4 * sizeof(uint4), "mfma_prepare stages 64 columns in the wave's list memory");

@@ -47,10 +47,10 @@ def test_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "rt_abi.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
         'sizeof(rt_sphere),sizeof(rt_material),sizeof(rt_camera),sizeof(rt_tile),'
         'sizeof(rt_request),sizeof(rt_frame),sizeof(rt_stats),sizeof(rt_ray_in),sizeof(rt_ray_out),'
-        'offsetof(rt_request,spheres),offsetof(rt_request,tiles));return 0;}\n')
+        'offsetof(rt_request,spheres),offsetof(rt_request,tiles),sizeof(rt_scan_info));return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True,
@@ -58,6 +58,6 @@ def test_struct_layouts_match_the_header(tmp_path):
     mine = [abi.SPHERE_DTYPE.itemsize, abi.MATERIAL_DTYPE.itemsize, C.sizeof(abi.RtCamera),
             abi.TILE_DTYPE.itemsize, C.sizeof(abi.RtRequest), C.sizeof(abi.RtFrame),
             C.sizeof(abi.RtStats), abi.RAY_IN_DTYPE.itemsize, abi.RAY_OUT_DTYPE.itemsize,
-            abi.RtRequest.spheres.offset, abi.RtRequest.tiles.offset]
+            abi.RtRequest.spheres.offset, abi.RtRequest.tiles.offset, C.sizeof(abi.RtScanInfo)]
     assert got == mine
     assert got[:4] == [20, 24, 128, 16]

@@ -22,7 +22,7 @@ def main():
     if os.path.exists(os.path.join(src, "bench.json")):
         shutil.copy(os.path.join(src, "bench.json"), dst + "_bench.json")
     rows = []
-    for name in ("fetch", "write", "sqA", "sqB"):
+    for name in ("fetch", "write", "sqA", "sqB", "sqC"):
         files = glob.glob(os.path.join(src, name, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             continue
