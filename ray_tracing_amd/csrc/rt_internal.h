@@ -28,7 +28,10 @@ constexpr int kThreadsSingle = RT_THREADS_SINGLE;
 constexpr int kThreadsAccel = RT_THREADS_ACCEL;   // workgroup of the hierarchy traversal
 // The scan on the matrix pipe: one workgroup of 16 waves per CU shares the sphere rows (64 bytes a
 // sphere), which two smaller workgroups could not both hold beside the waves' candidate lists.
-constexpr int kThreadsMfma = 1024;
+#ifndef RT_THREADS_MFMA
+#define RT_THREADS_MFMA 1024
+#endif
+constexpr int kThreadsMfma = RT_THREADS_MFMA;
 constexpr uint32_t kMfmaChunk = 512;               // spheres resident in LDS at a time
 constexpr uint32_t kMfmaBlock = 16;                // spheres per MFMA (rows of a 16x16x32 product)
 constexpr uint32_t kMfmaRows = kMfmaChunk + kMfmaBlock;   // + one block of read-ahead padding

@@ -14,6 +14,11 @@ run 11 1920 1080 128 0 2 glass
 run 11 1920 1080 1024 0 1 glass
 run 4 400 225 16 0 3
 run 11 1920 136 100 0 3
+# the filter kept on the vector ALU (flags = 8) on the three 1080p scenes and the rank share
+run 11 1920 1080 100 8 2
+run 50 1920 1080 64 8 2
+run 11 1920 1080 128 8 2 glass
+run 11 1920 136 100 8 3
 # the opt-in hierarchy traversal (flags = 4) on the three 1080p scenes
 run 11 1920 1080 100 4 2
 run 50 1920 1080 64 4 2
