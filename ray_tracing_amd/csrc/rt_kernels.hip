@@ -809,28 +809,26 @@ __device__ __forceinline__ void mfma_ray_column(const Path& P, bool ok, float sc
   }
 }
 
-// The columns of the wave's 128 paths as the instruction wants them: ray block j (paths
-// 16 j .. 16 j + 15 of the wave, path slot = lane + 64 r) in b[j], lane l holding slots
-// 8 (l >> 4) .. + 7 of ray l & 15.  Every lane builds the columns of its own two paths and the
-// wave passes them round through `stage` (4 KB of its candidate-list memory, empty just now).
-__device__ __forceinline__ void mfma_prepare(const Path (&P)[R], float scale, h8* stage, uint32_t lane,
-                                             h8 (&b)[8]) {
+// The columns of one half of the wave's paths (path slot r of every lane) as the instruction
+// wants them: ray block j (slots 64 r + 16 j .. + 15) in b[j], lane l holding slots
+// 8 (l >> 4) .. + 7 of ray l & 15.  Every lane builds the column of its own path and the wave
+// passes them round through `stage`: 4 KB of its own LDS that nothing else uses at that moment
+// (the published rays of the replay; the candidate list may hold entries already).
+__device__ __forceinline__ void mfma_prepare_half(const Path& P, float scale, h8* stage, uint32_t lane,
+                                                  h8 (&b)[4]) {
   const uint32_t c = lane & 15, g = lane >> 4;
+  h8 q[4];
+  mfma_ray_column(P, P.alive && !P.degenerate, scale, q);
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    h8 q[4];
-    mfma_ray_column(P[r], P[r].alive && !P[r].degenerate, scale, q);
+  for (int k = 0; k < 4; ++k) stage[lane * 4 + k] = q[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int k = 0; k < 4; ++k) stage[lane * 4 + k] = q[k];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) b[4 * r + jj] = stage[(16 * jj + c) * 4 + g];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
+  for (int jj = 0; jj < 4; ++jj) b[jj] = stage[(16 * jj + c) * 4 + g];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // What a chunk looks like in LDS for the matrix scan.
@@ -840,116 +838,111 @@ struct MfmaChunk {
   const uint32_t* index;   // [kMfmaChunk] sphere number in the World
 };
 
-// Scan one LDS-resident chunk: positions [0, n_rows) have rows, positions [n_rows, cn) are the
-// spheres listed for every ray.  b = mfma_prepare's columns of this step.
-__device__ __forceinline__ void scan_chunk_mfma(Path (&P)[R], const h8 (&b)[8], const MfmaChunk& m,
-                                                uint32_t n_rows, uint32_t cn, WaveLists& wl,
-                                                uint32_t lane, PhaseClock& clk) {
-  const uint32_t c = lane & 15, g = lane >> 4;
-  RT_MARK("scan");
-  // spheres outside the filter's range: one entry per scanned path
-  if (n_rows < cn) {
-    for (uint32_t li = n_rows; li < cn; ++li) {
+// The spheres outside the filter's range (positions [n_rows, cn) of the chunk): one entry per
+// scanned path.
+__device__ __forceinline__ void mfma_list_always(Path (&P)[R], const MfmaChunk& m, uint32_t n_rows,
+                                                 uint32_t cn, WaveLists& wl, uint32_t lane,
+                                                 PhaseClock& clk) {
+  for (uint32_t li = n_rows; li < cn; ++li) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const bool okl = P[r].alive && !P[r].degenerate;
-        const unsigned long long mm = __builtin_amdgcn_ballot_w64(okl);
-        const uint32_t k = (uint32_t)__builtin_popcountll(mm);
-        if (k == 0) continue;
-        if (wl.count + k > L) replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
-        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-        if (okl) wl.list[wl.count + at] = lane | ((li * R + r) << 6);
-        wl.count += k;
-      }
+    for (int r = 0; r < R; ++r) {
+      const bool okl = P[r].alive && !P[r].degenerate;
+      const unsigned long long mm = __builtin_amdgcn_ballot_w64(okl);
+      const uint32_t k = (uint32_t)__builtin_popcountll(mm);
+      if (k == 0) continue;
+      if (wl.count + k > L) replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
+      const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+      if (okl) wl.list[wl.count + at] = lane | ((li * R + r) << 6);
+      wl.count += k;
     }
   }
+}
+
+// One pass over the chunk's rows for one half of the wave's paths (path slot `half` of every
+// lane; b = mfma_prepare_half's columns).  Sixteen results per lane at a time, for 16 spheres x
+// 64 paths; thirty-two at a time (both halves) does not fit the register budget.
+__device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], uint32_t half,
+                                               const MfmaChunk& m, uint32_t n_rows, WaveLists& wl,
+                                               uint32_t lane, PhaseClock& clk) {
+  const uint32_t c = lane & 15, g = lane >> 4;
+  RT_MARK("scan");
   RT_PRIO_MFMA();
-  bool scanned[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) scanned[r] = __builtin_amdgcn_ballot_w64(P[r].alive && !P[r].degenerate) != 0;
   const f4v zero = {0.0f, 0.0f, 0.0f, 0.0f};
   h8 a = m.rows[g * kMfmaRows + c];
   for (uint32_t blk = 0; blk < n_rows; blk += kMfmaBlock) {
-    const h8 a_now = a;
+    f4v acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], zero, 0, 0, 0);
     a = m.rows[g * kMfmaRows + blk + kMfmaBlock + c];   // read ahead (the rows are padded by a block)
-    // The wave's 128 paths in two halves of four ray blocks (path slot r = 0, then r = 1): sixteen
-    // results per lane at a time instead of thirty-two keeps the loop inside the register budget.
+    // Result i of ray block j is v[4 i + j]: sphere blk + 4 g + i against the path in slot
+    // 64 half + 16 j + c.  A float that is not negative is an integer that is not negative:
+    // the maximum of the 16 as integers says whether this lane has any candidate at all.
+    int v[16];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (!scanned[half]) continue;   // wave-uniform: no path of this half is being scanned
-      f4v acc[4];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, b[4 * half + j], zero, 0, 0, 0);
-      // Result i of ray block j is v[4 i + j]: sphere blk + 4 g + i against the path in slot
-      // 64 half + 16 j + c.  A float that is not negative is an integer that is not negative:
-      // the maximum of the 16 as integers says whether this lane has any candidate at all.
-      int v[16];
+      for (int i = 0; i < 4; ++i) v[4 * i + j] = __float_as_int(acc[j][i]);
+    int top = v[0];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[4 * i + j] = __float_as_int(acc[j][i]);
-      int top = v[0];
-#pragma unroll
-      for (int k = 1; k + 1 < 16; k += 2) top = max(max(top, v[k]), v[k + 1]);
-      top = max(top, v[15]);
+    for (int k = 1; k + 1 < 16; k += 2) top = max(max(top, v[k]), v[k + 1]);
+    top = max(top, v[15]);
 #ifdef RT_DIAG_PHASES
-      clk.blocks++;
+    clk.blocks++;
 #endif
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(top >= 0) != 0, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(top >= 0) != 0, 0)) {
 #ifdef RT_DIAG_PHASES
-        clk.trig_blocks++;
+      clk.trig_blocks++;
 #endif
-        uint32_t neg = 0;   // bit q = sign of v[q]
+      uint32_t neg = 0;   // bit q = sign of v[q]
 #pragma unroll
-        for (int q = 15; q >= 0; --q) neg = __builtin_amdgcn_alignbit(neg, (uint32_t)v[q], 31);
-        uint32_t cand = ~neg & 0xFFFFu;
-        // an entry = sphere position << 7 | path slot: the lane's base + (i << 7 | j << 4), q = 4 i + j
-        const uint32_t base = ((blk + 4u * g) << 7) | ((uint32_t)half << 6) | c;
-        for (;;) {
-          // every lane's entries go behind those of the lanes below it
-          const uint32_t mine = (uint32_t)__builtin_popcount(cand);
-          uint32_t inc = mine;
-          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);    // row_shr:1
-          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);    // row_shr:2
-          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true);    // row_shr:4
-          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true);    // row_shr:8
-          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15
-          inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
-          const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+      for (int q = 15; q >= 0; --q) neg = __builtin_amdgcn_alignbit(neg, (uint32_t)v[q], 31);
+      uint32_t cand = ~neg & 0xFFFFu;
+      // an entry = sphere position << 7 | path slot: the lane's base + (i << 7 | j << 4), q = 4 i + j
+      const uint32_t base = ((blk + 4u * g) << 7) | (half << 6) | c;
+      for (;;) {
+        // every lane's entries go behind those of the lanes below it
+        const uint32_t mine = (uint32_t)__builtin_popcount(cand);
+        uint32_t inc = mine;
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);    // row_shr:1
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);    // row_shr:2
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true);    // row_shr:4
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true);    // row_shr:8
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
 #ifdef RT_DIAG_PHASES
-          clk.trig_pairs += all;
+        clk.trig_pairs += all;
 #endif
-          const uint32_t room = L - wl.count;
-          uint32_t at = wl.count + inc - mine;
-          while (cand != 0 && at < L) {
-            const uint32_t q = (uint32_t)__builtin_ctz(cand);
-            cand &= cand - 1;
-            wl.list[at] = base + ((q << 5) & 0x180u) + ((q & 3u) << 4);
-            ++at;
-          }
-          if (all <= room) {
-            wl.count += all;
-            break;
-          }
-          // the list is full: replay it, then list what did not fit (still set in `cand`)
-          wl.count = L;
-          RT_STAMP(clk.scan, clk.t0);
-          RT_PRIO_REST();
-          replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
-          RT_STAMP(clk.replay, clk.t0);
-          RT_PRIO_MFMA();
+        const uint32_t room = L - wl.count;
+        uint32_t at = wl.count + inc - mine;
+        while (cand != 0 && at < L) {
+          const uint32_t q = (uint32_t)__builtin_ctz(cand);
+          cand &= cand - 1;
+          wl.list[at] = base + ((q << 5) & 0x180u) + ((q & 3u) << 4);
+          ++at;
         }
+        if (all <= room) {
+          wl.count += all;
+          break;
+        }
+        // the list is full: replay it, then list what did not fit (still set in `cand`)
+        wl.count = L;
+        RT_STAMP(clk.scan, clk.t0);
+        RT_PRIO_REST();
+        replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
+        RT_STAMP(clk.replay, clk.t0);
+        RT_PRIO_MFMA();
       }
     }
   }
   RT_STAMP(clk.scan, clk.t0);
   RT_PRIO_REST();
-  RT_MARK("replay");
-  replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
-  RT_MARK("replay_end");
-  RT_STAMP(clk.replay, clk.t0);
+}
+
+// Does any lane scan its path in slot r?
+__device__ __forceinline__ bool mfma_half_scanned(const Path& P) {
+  return __builtin_amdgcn_ballot_w64(P.alive && !P.degenerate) != 0;
 }
 
 // Zero, non-finite or out-of-range rays of the matrix scan: World::hit's loop as written
@@ -1531,18 +1524,47 @@ void trace_kernel(const TraceParams p) {
       else bvh_hit<false>(P[0], p.scene, bvh_src, bvh_stack, bvh_interior, bvh_tests);
       RT_STAMP(clk.scan, clk.t0);   // the traversal is this mode's "scan"
     } else if constexpr (MFMA) {
-      h8 cols[8];
-      if (!tail) mfma_prepare(P, p.scene.mfma_scale, reinterpret_cast<h8*>(wl.list), lane, cols);
       const uint32_t n_in = n - p.scene.mfma_always;   // positions with rows; the rest are listed
-      for (uint32_t base = 0, chunk = 0; base < n; base += kMfmaChunk, ++chunk) {
-        const uint32_t cn = n - base < kMfmaChunk ? n - base : kMfmaChunk;
-        if (MULTI) {
+      h8* stage = reinterpret_cast<h8*>(wl.rays);
+      if constexpr (MULTI) {
+        // several chunks: the columns of both halves are built once and kept across the chunks
+        h8 cols[R][4];
+        if (!tail) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) mfma_prepare_half(P[r], p.scene.mfma_scale, stage, lane, cols[r]);
+        }
+        for (uint32_t base = 0, chunk = 0; base < n; base += kMfmaChunk, ++chunk) {
+          const uint32_t cn = n - base < kMfmaChunk ? n - base : kMfmaChunk;
           __syncthreads();   // every wave is done with the previous chunk
           stage_chunk_mfma(p.scene, chunk, cn, mrows, mgeom, mindex);
           __syncthreads();
+          const uint32_t n_rows = base >= n_in ? 0u : (n_in - base < cn ? n_in - base : cn);
+          if (!tail) {
+            mfma_list_always(P, mc, n_rows, cn, wl, lane, clk);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              if (mfma_half_scanned(P[r])) scan_pass_mfma(P, cols[r], (uint32_t)r, mc, n_rows, wl, lane, clk);
+            RT_MARK("replay");
+            replay_lists<true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index);
+            RT_MARK("replay_end");
+            RT_STAMP(clk.replay, clk.t0);
+          }
         }
-        const uint32_t n_rows = base >= n_in ? 0u : (n_in - base < cn ? n_in - base : cn);
-        if (!tail) scan_chunk_mfma(P, cols, mc, n_rows, cn, wl, lane, clk);
+      } else if (!tail) {
+        // one chunk: a half's columns are built right before its pass, so that only four
+        // operands (16 VGPRs) are alive at a time
+        mfma_list_always(P, mc, n_in, n, wl, lane, clk);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (!mfma_half_scanned(P[r])) continue;
+          h8 cols[4];
+          mfma_prepare_half(P[r], p.scene.mfma_scale, stage, lane, cols);
+          scan_pass_mfma(P, cols, (uint32_t)r, mc, n_in, wl, lane, clk);
+        }
+        RT_MARK("replay");
+        replay_lists<true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index);
+        RT_MARK("replay_end");
+        RT_STAMP(clk.replay, clk.t0);
       }
       if (tail) {
         // the tail step's filter is the vector form: its constants are formed here, on demand
@@ -1783,8 +1805,10 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     mc.rows = reinterpret_cast<const h8*>(mrows);
     mc.geom = mgeom;
     mc.index = mindex;
-    h8 cols[8];
-    mfma_prepare(P, p.scene.mfma_scale, reinterpret_cast<h8*>(wl.list), lane, cols);
+    h8 cols[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      mfma_prepare_half(P[r], p.scene.mfma_scale, reinterpret_cast<h8*>(wl.rays), lane, cols[r]);
     const uint32_t n_in = n - p.scene.mfma_always;
     PhaseClock clk = {};
     for (uint32_t base = 0, chunk = 0; base < n; base += kMfmaChunk, ++chunk) {
@@ -1793,7 +1817,11 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
       stage_chunk_mfma(p.scene, chunk, cn, mrows, mgeom, mindex);
       __syncthreads();
       const uint32_t n_rows = base >= n_in ? 0u : (n_in - base < cn ? n_in - base : cn);
-      scan_chunk_mfma(P, cols, mc, n_rows, cn, wl, lane, clk);
+      mfma_list_always(P, mc, n_rows, cn, wl, lane, clk);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (mfma_half_scanned(P[r])) scan_pass_mfma(P, cols[r], (uint32_t)r, mc, n_rows, wl, lane, clk);
+      replay_lists<true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index);
     }
     literal_world_hit(P, p.scene);
   } else if (p.accel) {
@@ -1885,7 +1913,7 @@ static_assert((size_t)4 * kMfmaRows * sizeof(uint4) +
                       (size_t)kMfmaChunk * (sizeof(float4) + sizeof(uint32_t) + sizeof(float)) +
                       queue_bytes(kThreadsMfma) + 256 <= 160 * 1024,
               "the matrix scan's workgroup must fit into a CU's LDS");
-static_assert(kWaveLdsBytes >= 64 * 4 * sizeof(uint4), "mfma_prepare stages 64 columns in the wave's list memory");
+static_assert((size_t)kSlots * 2 * sizeof(float4) >= 64 * 4 * sizeof(uint4), "mfma_prepare_half stages 64 columns in the wave's published-ray memory");
 
 uint32_t bvh_stack_depth() { return kBvhStack; }
 
