@@ -114,8 +114,11 @@ static_assert(R == 2, "an entry keeps the path slot in 7 bits: lane | r << 6");
 static_assert(L >= (uint32_t)(U * R * kWave), "an empty list must take whatever one block can add");
 // A list that holds more than this is replayed before the scan goes on.
 constexpr uint32_t kListMark = L - (uint32_t)kWave;
-constexpr size_t kWaveLdsBytes = (size_t)L * sizeof(uint32_t) + (size_t)kSlots * sizeof(unsigned long long) +
-                                 (size_t)kSlots * 2 * sizeof(float4);
+constexpr size_t kWaveListBytes = (size_t)L * sizeof(uint32_t) + (size_t)kSlots * sizeof(unsigned long long) +
+                                  (size_t)kSlots * 2 * sizeof(float4);
+// ... and, last, the list's length while the matrix scan appends to it (16 bytes keep the next
+// wave's list aligned)
+constexpr size_t kWaveLdsBytes = kWaveListBytes + 16;
 constexpr unsigned long long kNoHit = ~0ull;
 constexpr float kTMin = 0.001f;  // src/main.rs:196
 constexpr float kTMax = FLT_MAX; // f32::MAX, src/main.rs:196
@@ -419,6 +422,11 @@ struct WaveLists {
   uint32_t* list;               // [L]
   unsigned long long* keys;     // [kSlots]
   float4* rays;                 // [kSlots][2]: (ox, oy, oz, a), (dx, dy, dz, -)
+  uint32_t* counter;            // [0] the list's length, valid inside scan_pass_mfma only
+                                // [1] "keys live": not zero when the keys hold the paths' best hits
+                                //     of this step so far (a replay without collection has run).
+                                //     In LDS rather than a register so that the scan pass's
+                                //     loop carries no state for its rare replay
   uint32_t count;               // entries in the list, wave-uniform
   uint32_t redo_from;           // first sphere of a block whose candidates did not all fit, or kNone
 };
@@ -553,52 +561,64 @@ __device__ __forceinline__ bool candidate_root(float4 s, V3 o, V3 d, float a, fl
 // PERM: the records in LDS are (cx, cy, cz, r*r) in the matrix scan's own sphere order, and
 // `index` maps a position in the chunk to the sphere's number in the World (which is what the
 // tie rule and the shading want).
-template <bool PERM = false>
+// COLLECT = false leaves the paths' best hits in the keys (wl.keys_live) instead of taking them
+// back into registers, for a replay in the middle of a scan pass: the pass's loop then changes no
+// path state, and the replay that ends the step starts from those keys and collects.
+template <bool PERM = false, bool COLLECT = true>
 __device__ __forceinline__ void replay_lists(Path (&P)[R], const float4* sph, const float* sr2,
                                              uint32_t chunk_base, WaveLists& wl, uint32_t lane,
                                              PhaseClock& clk, const uint32_t* index = nullptr) {
   const uint32_t n = wl.count;
-  if (n == 0) return;   // wave-uniform
+  // wave-uniform: every lane reads the same word
+  const bool keys_live = __builtin_amdgcn_readfirstlane((int)wl.counter[1]) != 0;
+  if (n == 0 && !(COLLECT && keys_live)) return;
+  if (n != 0) {
 #ifdef RT_DIAG_PHASES
-  if (lane == 0) clk.cand += n;   // summed over lanes at the end
+    if (lane == 0) clk.cand += n;   // summed over lanes at the end
 #endif
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const uint32_t slot = (uint32_t)r * kWave + lane;
-    wl.rays[2 * slot] = make_float4(P[r].ox, P[r].oy, P[r].oz, P[r].a);
-    wl.rays[2 * slot + 1] = make_float4(P[r].dx, P[r].dy, P[r].dz, 0.0f);
-    wl.keys[slot] = P[r].best == kNone ? kNoHit : hit_key(P[r].closest, P[r].best);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (uint32_t j = 0; j < n; j += kWave) {
+    for (int r = 0; r < R; ++r) {
+      const uint32_t slot = (uint32_t)r * kWave + lane;
+      wl.rays[2 * slot] = make_float4(P[r].ox, P[r].oy, P[r].oz, P[r].a);
+      wl.rays[2 * slot + 1] = make_float4(P[r].dx, P[r].dy, P[r].dz, 0.0f);
+      if (!keys_live) wl.keys[slot] = P[r].best == kNone ? kNoHit : hit_key(P[r].closest, P[r].best);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t j = 0; j < n; j += kWave) {
 #ifdef RT_DIAG_PHASES
-    clk.replay_iters++;
+      clk.replay_iters++;
 #endif
-    if (j + lane < n) {
-      const uint32_t e = wl.list[j + lane];
-      const uint32_t slot = e & (kSlots - 1), li = e >> 7;
-      const float4 ro = wl.rays[2 * slot], rd = wl.rays[2 * slot + 1];
-      const unsigned long long now = wl.keys[slot];
-      const float closest = now == kNoHit ? kTMax : __uint_as_float((uint32_t)(now >> 32));
-      float4 rec = sph[li];
-      if (!PERM) rec.w = sr2[li];
-      float root;
-      if (candidate_root(rec, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), ro.w, closest, &root))
-        atomicMin(&wl.keys[slot], hit_key(root, PERM ? index[li] : chunk_base + li));
+      if (j + lane < n) {
+        const uint32_t e = wl.list[j + lane];
+        const uint32_t slot = e & (kSlots - 1), li = e >> 7;
+        const float4 ro = wl.rays[2 * slot], rd = wl.rays[2 * slot + 1];
+        const unsigned long long now = wl.keys[slot];
+        const float closest = now == kNoHit ? kTMax : __uint_as_float((uint32_t)(now >> 32));
+        float4 rec = sph[li];
+        if (!PERM) rec.w = sr2[li];
+        float root;
+        if (candidate_root(rec, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), ro.w, closest, &root))
+          atomicMin(&wl.keys[slot], hit_key(root, PERM ? index[li] : chunk_base + li));
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (COLLECT) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const unsigned long long mine = wl.keys[(uint32_t)r * kWave + lane];
-    if (mine != kNoHit) {
-      P[r].closest = __uint_as_float((uint32_t)(mine >> 32));
-      P[r].best = 0xFFFFFFFFu - (uint32_t)mine;
+    for (int r = 0; r < R; ++r) {
+      const unsigned long long mine = wl.keys[(uint32_t)r * kWave + lane];
+      if (mine != kNoHit) {
+        P[r].closest = __uint_as_float((uint32_t)(mine >> 32));
+        P[r].best = 0xFFFFFFFFu - (uint32_t)mine;
+      }
     }
+    if (keys_live) wl.counter[1] = 0u;
+  } else {
+    wl.counter[1] = 1u;
   }
   wl.count = 0;
 }
@@ -809,6 +829,8 @@ __device__ __forceinline__ void mfma_ray_column(const Path& P, bool ok, float sc
   }
 }
 
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t v);
+
 // The columns of one half of the wave's paths (path slot r of every lane) as the instruction
 // wants them: ray block j (slots 64 r + 16 j .. + 15) in b[j], lane l holding slots
 // 8 (l >> 4) .. + 7 of ray l & 15.  Every lane builds the column of its own path and the wave
@@ -819,13 +841,18 @@ __device__ __forceinline__ void mfma_prepare_half(const Path& P, float scale, h8
   const uint32_t c = lane & 15, g = lane >> 4;
   h8 q[4];
   mfma_ray_column(P, P.alive && !P.degenerate, scale, q);
+  // A column is 64 bytes, so lanes that follow each other would all start in the same two
+  // banks: quarter k of ray l sits at place k ^ sw(l) of its column instead, with sw chosen so
+  // that any 8 (or 16) consecutive rays spread one quarter over all 32 (or 64) banks, on the
+  // way in (one ray per lane) and on the way out (16 consecutive rays per quarter).
+  const uint32_t sw = ((c >> 1) + (c >> 3)) & 3u;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) stage[lane * 4 + k] = q[k];
+  for (int k = 0; k < 4; ++k) stage[lane * 4 + ((uint32_t)k ^ sw)] = q[k];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) b[jj] = stage[(16 * jj + c) * 4 + g];
+  for (int jj = 0; jj < 4; ++jj) b[jj] = stage[(16 * jj + c) * 4 + (g ^ sw)];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -869,6 +896,7 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], u
   RT_MARK("scan");
   RT_PRIO_MFMA();
   const f4v zero = {0.0f, 0.0f, 0.0f, 0.0f};
+  __hip_atomic_store(wl.counter, wl.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   h8 a = m.rows[g * kMfmaRows + c];
   for (uint32_t blk = 0; blk < n_rows; blk += kMfmaBlock) {
     f4v acc[4];
@@ -894,48 +922,66 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], u
 #ifdef RT_DIAG_PHASES
       clk.trig_blocks++;
 #endif
-      uint32_t neg = 0;   // bit q = sign of v[q]
+      // The sign of result (i, j) goes to bit 8 i + j of a mask: four short chains of
+      // v_alignbit_b32 that do not wait for each other, and an entry of the list is then the
+      // lane's base plus the bit's number times 16 (sphere position << 7 | path slot).
+      uint32_t neg = 0;
 #pragma unroll
-      for (int q = 15; q >= 0; --q) neg = __builtin_amdgcn_alignbit(neg, (uint32_t)v[q], 31);
-      uint32_t cand = ~neg & 0xFFFFu;
-      // an entry = sphere position << 7 | path slot: the lane's base + (i << 7 | j << 4), q = 4 i + j
-      const uint32_t base = ((blk + 4u * g) << 7) | (half << 6) | c;
+      for (int i = 3; i >= 0; --i) {
+        uint32_t ni = 0;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) ni = __builtin_amdgcn_alignbit(ni, (uint32_t)v[4 * i + j], 31);
+        neg = (neg << 8) | ni;
+      }
+      uint32_t cand = ~neg & 0x0F0F0F0Fu;
+      // (the lane's own part of an entry is formed here, from a lane number the compiler cannot
+      // move out of the loop: a register less to keep across the pass)
+      uint32_t zero = 0;
+      asm volatile("" : "+v"(zero));
+      const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+      const uint32_t base = (blk << 7) | (half << 6) | ((ln >> 4) << 9) | (ln & 15u);
       for (;;) {
-        // every lane's entries go behind those of the lanes below it
+        // A lane with candidates reserves its run of the list with one LDS atomic on the list's
+        // length (the order of the entries does not matter to the replay).
         const uint32_t mine = (uint32_t)__builtin_popcount(cand);
-        uint32_t inc = mine;
-        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);    // row_shr:1
-        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);    // row_shr:2
-        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true);    // row_shr:4
-        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true);    // row_shr:8
-        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15
-        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
-        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        uint32_t at = 0;
+        if (mine != 0)
+          at = __hip_atomic_fetch_add(wl.counter, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #ifdef RT_DIAG_PHASES
-        clk.trig_pairs += all;
+        clk.trig_pairs += wave_sum(mine);
 #endif
-        const uint32_t room = L - wl.count;
-        uint32_t at = wl.count + inc - mine;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(at + mine > L) == 0, 1)) {
+          uint32_t* dst = wl.list + at;
+          while (cand != 0) {
+            const uint32_t q = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1;
+            *dst++ = base + (q << 4);
+          }
+          break;
+        }
+        // The list is full.  Runs that end below its end are written whole, the one that
+        // straddles the end as far as it fits (so every place up to the end holds an entry), the
+        // list is replayed, and what did not fit (still set in `cand`) is reserved again.
         while (cand != 0 && at < L) {
           const uint32_t q = (uint32_t)__builtin_ctz(cand);
           cand &= cand - 1;
-          wl.list[at] = base + ((q << 5) & 0x180u) + ((q & 3u) << 4);
+          wl.list[at] = base + (q << 4);
           ++at;
         }
-        if (all <= room) {
-          wl.count += all;
-          break;
-        }
-        // the list is full: replay it, then list what did not fit (still set in `cand`)
         wl.count = L;
         RT_STAMP(clk.scan, clk.t0);
         RT_PRIO_REST();
-        replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
+        replay_lists<true, false>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
         RT_STAMP(clk.replay, clk.t0);
         RT_PRIO_MFMA();
+        __hip_atomic_store(wl.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (__builtin_amdgcn_ballot_w64(cand != 0) == 0) break;
       }
     }
   }
+  // LDS operations of one wave complete in order: this read sees every reservation above
+  wl.count = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)__hip_atomic_load(wl.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT));
   RT_STAMP(clk.scan, clk.t0);
   RT_PRIO_REST();
 }
@@ -1411,7 +1457,9 @@ void trace_kernel(const TraceParams p) {
   wl.keys = reinterpret_cast<unsigned long long*>(wave_lds + (size_t)L * sizeof(uint32_t));
   wl.rays = reinterpret_cast<float4*>(wave_lds + (size_t)L * sizeof(uint32_t) +
                                       (size_t)kSlots * sizeof(unsigned long long));
+  wl.counter = reinterpret_cast<uint32_t*>(wave_lds + kWaveListBytes);
   wl.count = 0;
+  wl.counter[1] = 0u;
   wl.redo_from = kNone;
 
   if (!MULTI && !ACCEL) {
@@ -1774,7 +1822,9 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
   wl.keys = reinterpret_cast<unsigned long long*>(wave_lds + (size_t)L * sizeof(uint32_t));
   wl.rays = reinterpret_cast<float4*>(wave_lds + (size_t)L * sizeof(uint32_t) +
                                       (size_t)kSlots * sizeof(unsigned long long));
+  wl.counter = reinterpret_cast<uint32_t*>(wave_lds + kWaveListBytes);
   wl.count = 0;
+  wl.counter[1] = 0u;
   wl.redo_from = kNone;
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   const bool live = i < p.n_rays;
