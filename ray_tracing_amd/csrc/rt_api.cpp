@@ -1121,6 +1121,7 @@ int rt_get_phase_cycles(uint64_t* out16) {
 #ifdef RT_DIAG_TRIGGERS
   // developer build: slots 8-10 carry the scan's branch statistics instead of drain steps
   for (int i = 0; i < 3; ++i) out16[8 + i] = c.phase[16 + i];
+  out16[11] = c.phase[19];   // wave-cycles inside the matrix scan's candidate code
 #endif
   return RT_OK;
 }

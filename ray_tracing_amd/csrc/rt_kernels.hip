@@ -92,6 +92,7 @@ struct PhaseClock {
   unsigned long long t_start, t_exhausted, tail_steps;
   unsigned long long drain_scan_steps, tail_cycles;
   unsigned long long cand, replay_iters;   // queued candidates (per lane), replay loop trips (per wave)
+  unsigned long long trig_cycles, prep_cycles;   // diagnostic: inside the candidate code, building columns
   unsigned long long blocks, trig_blocks, trig_pairs;   // scan blocks, those that branched to the
                                                         // queueing code, (sphere, path) pairs queued there
 };
@@ -921,6 +922,7 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], u
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(top >= 0) != 0, 0)) {
 #ifdef RT_DIAG_PHASES
       clk.trig_blocks++;
+      const unsigned long long trig_t0 = __builtin_amdgcn_s_memtime();
 #endif
       // The sign of result (i, j) goes to bit 8 i + j of a mask: four short chains of
       // v_alignbit_b32 that do not wait for each other, and an entry of the list is then the
@@ -948,7 +950,7 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], u
         if (mine != 0)
           at = __hip_atomic_fetch_add(wl.counter, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #ifdef RT_DIAG_PHASES
-        clk.trig_pairs += wave_sum(mine);
+        clk.trig_pairs += mine;   // per lane; summed over the wave at the end
 #endif
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(at + mine > L) == 0, 1)) {
           uint32_t* dst = wl.list + at;
@@ -977,6 +979,9 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], u
         __hip_atomic_store(wl.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         if (__builtin_amdgcn_ballot_w64(cand != 0) == 0) break;
       }
+#ifdef RT_DIAG_PHASES
+      clk.trig_cycles += __builtin_amdgcn_s_memtime() - trig_t0;
+#endif
     }
   }
   // LDS operations of one wave complete in order: this read sees every reservation above
@@ -1606,7 +1611,13 @@ void trace_kernel(const TraceParams p) {
         for (int r = 0; r < R; ++r) {
           if (!mfma_half_scanned(P[r])) continue;
           h8 cols[4];
+#ifdef RT_DIAG_PHASES
+          const unsigned long long prep_t0 = __builtin_amdgcn_s_memtime();
+#endif
           mfma_prepare_half(P[r], p.scene.mfma_scale, stage, lane, cols);
+#ifdef RT_DIAG_PHASES
+          clk.prep_cycles += __builtin_amdgcn_s_memtime() - prep_t0;
+#endif
           scan_pass_mfma(P, cols, (uint32_t)r, mc, n_in, wl, lane, clk);
         }
         RT_MARK("replay");
@@ -1704,16 +1715,21 @@ void trace_kernel(const TraceParams p) {
     atomicAdd(&p.counters->phase[9], clk.tail_steps);            // drain steps in tail mode
     atomicMax(&p.counters->phase[10], clk.drain_scan_steps);
     atomicMax(&p.counters->phase[11], clk.tail_steps);
+#ifndef RT_DIAG_TRIGGERS
     atomicAdd(&p.counters->phase[12], clk.tail_cycles);          // cycles inside tail_hit
+#endif
     atomicAdd(&p.counters->phase[13], 1ull);                     // waves
   }
 #ifdef RT_DIAG_TRIGGERS
   // a build for reading the scan's branch rate: {scan blocks, blocks that branched to the
   // queueing code, (sphere, path) pairs queued there}, summed over waves
+  const unsigned long long pairs = MFMA ? wave_sum((uint32_t)clk.trig_pairs) : clk.trig_pairs;
   if (lane == 0) {
     atomicAdd(&p.counters->phase[16], clk.blocks);
     atomicAdd(&p.counters->phase[17], clk.trig_blocks);
-    atomicAdd(&p.counters->phase[18], clk.trig_pairs);
+    atomicAdd(&p.counters->phase[18], pairs);
+    atomicAdd(&p.counters->phase[19], clk.trig_cycles);
+    atomicAdd(&p.counters->phase[12], clk.prep_cycles);   // (this build reports no tail cycles)
   }
 #endif
   {

@@ -37,6 +37,8 @@ def main():
           % (blocks / max(steps, 1), 100 * trig / max(blocks, 1), pairs / max(trig, 1),
              ph[14] / max(st.rays, 1), ph[15] / max(st.rays, 1)))
     tot = ph[:4].sum()
+    print("of the wave time: candidate code inside the scan %.1f%%, building ray columns %.1f%%"
+          % (100 * ph[11] / tot, 100 * ph[12] / tot))
     print("wave time: refill %.1f%% scan %.1f%% replay %.1f%% shade %.1f%%"
           % tuple(100 * ph[i] / tot for i in range(4)))
 
