@@ -578,6 +578,24 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   }
   p.counters = slot->counters;
 
+  // Equal row blocks at a constant pitch (a rank's share of a frame): the trace kernel takes
+  // them as one tile with a rule for its rows, and looks nothing up per work item.
+  bool row_blocks = n_tiles > 1 && tiles[0].h > 0;
+  for (size_t i = 1; row_blocks && i < n_tiles; ++i) {
+    const rt::TileDev &a = tiles[0], &b = tiles[i];
+    row_blocks = b.x == a.x && b.w == a.w && b.out_stride == a.out_stride &&
+                 (b.h == a.h || (i + 1 == n_tiles && b.h <= a.h && b.h > 0)) &&
+                 b.first_pixel == (uint64_t)i * a.w * a.h && tiles[1].y > a.y &&
+                 b.y == a.y + i * (uint64_t)(tiles[1].y - a.y) && tiles[1].out_offset > a.out_offset &&
+                 b.out_offset == a.out_offset + i * (tiles[1].out_offset - a.out_offset);
+  }
+  if (row_blocks) {
+    p.row_block = tiles[0].h;
+    p.row_period = tiles[1].y - tiles[0].y;
+    p.out_period = tiles[1].out_offset - tiles[0].out_offset;
+    p.row_block_div = rt::make_divider(p.row_block);
+    if (p.out_period >= 0xFFFFFFFFull) row_blocks = false, p.row_block = 0;
+  }
   if (n_tiles == 1) {
     p.tile0 = tiles[0];
     p.tiles = nullptr;
@@ -610,6 +628,10 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   rp.total_pixels = p.total_pixels;
   rp.tile0 = p.tile0;
   rp.tiles = p.tiles;
+  if (row_blocks) {   // (the reduce kernel keeps the list; only the trace kernel takes the rule)
+    p.n_tiles = 1;
+    p.tile0 = tiles[0];
+  }
   rp.resolve = resolve;
   rp.accumulate = accumulate ? 1 : 0;
   rp.inv_spp = p.inv_spp;

@@ -192,6 +192,13 @@ struct TraceParams {
   uint64_t out_pixels;      // pixels the output spans (its last covered pixel + 1)
   TileDev tile0;            // the tile list when n_tiles == 1
   const TileDev* tiles;     // otherwise
+  // A list of equal row blocks at a constant pitch (one rank's share of a frame dealt out in
+  // blocks of rows) is passed as ONE tile, tile0 = the first block with all the list's rows:
+  // row ty of the list is row ty % row_block of block ty / row_block, which starts row_period
+  // image rows and out_period output pixels after the block before it.  0: an ordinary tile.
+  uint32_t row_block, row_period;
+  uint64_t out_period;
+  Divider row_block_div;
   float* out;               // final buffer (slices == 1) or partial-sum buffer
   int resolve;              // apply x*(1/spp), sqrt, clamp on the way out (slices == 1 only)
   uint32_t bvh_stack;       // RT_FLAG_ACCEL: rows of the traversal stack (levels of the tree)

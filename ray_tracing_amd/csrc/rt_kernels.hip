@@ -1352,7 +1352,14 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TracePa
   const uint32_t local = g - t.first_pixel;
   const uint32_t ty = fast_div(local, t.wdiv);
   const uint32_t tx = local - ty * t.w;
-  const uint32_t px = t.x + tx, py = t.y + ty;
+  uint32_t px = t.x + tx, py = t.y + ty;
+  uint32_t at = (uint32_t)t.out_offset + ty * t.out_stride + tx;
+  if (p.row_block != 0) {   // equal row blocks at a constant pitch, passed as one tile
+    const uint32_t blk = fast_div(ty, p.row_block_div);
+    const uint32_t row = ty - blk * p.row_block;
+    py = t.y + blk * p.row_period + row;
+    at = (uint32_t)t.out_offset + blk * (uint32_t)p.out_period + row * t.out_stride + tx;
+  }
   P.fx = (float)px;
   P.fy = (float)py;
   P.pixel = py * p.width + px;
@@ -1360,7 +1367,6 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TracePa
   // `sl` of the pixel's run of `slices` partial sums.  The items a wave reserves together are
   // the slices of one or two pixels, so their stores fill whole cache lines of one L2.  All
   // below 2^32 (checked on the host), so 32-bit arithmetic does.
-  const uint32_t at = (uint32_t)t.out_offset + ty * t.out_stride + tx;
   P.out_index = p.slices != 1 ? at * p.slices + sl : at;
   P.sample = p.slice_begin[sl];
   P.sample_end = p.slice_begin[sl + 1];

@@ -142,6 +142,41 @@ def test_4k_500spp_eight_row_shares_reassemble_to_the_whole_frame():
     scene.close()
 
 
+@pytest.mark.parametrize("flags", [0, SEQ])
+def test_row_block_lists_regular_ragged_and_irregular(flags):
+    """Tile lists made of row blocks: at a constant pitch (what the trace kernel takes as one
+    tile with a rule for its rows), the same with a short last block, and at an uneven pitch
+    (looked up tile by tile).  Each equals the same rows of the frame rendered whole."""
+    w, h, spp = 160, 100, 6
+    world = host.create_random_world(1, (-4, 4))
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
+    scene = hip.Scene(world.spheres, world.materials)
+    frame = hip.make_frame(camera.m, w, h, spp, 50, 3, flags=flags)
+    stream = torch.cuda.current_stream().cuda_stream
+    full = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    hip.render_rows_device_async(scene, frame, 0, h, True, full.data_ptr(), stream)
+    torch.cuda.synchronize()
+    plan = multi_gpu.RowPlan(w, h, 3)                 # 12 blocks of 8 rows and one of 4
+    lists = [plan.tiles_for(r) for r in range(3)]     # rank 0's last block is the short one
+    assert int(lists[0][0]["height"][-1]) == 4
+    # uneven pitch: blocks 0, 1, 4, 5 and 11
+    blocks = [0, 1, 4, 5, 11]
+    t = np.array([(0, 8 * b, w, 8) for b in blocks], dtype=abi.TILE_DTYPE)
+    lists.append((t, np.arange(len(blocks), dtype=np.uint64) * 8 * w, np.full(len(blocks), w, dtype=np.uint32)))
+    # constant pitch in the image but not in the output (a gap after the second block)
+    t = np.array([(0, 16 * k, w, 8) for k in range(4)], dtype=abi.TILE_DTYPE)
+    lists.append((t, np.array([0, 8 * w, 24 * w, 32 * w], dtype=np.uint64), np.full(4, w, dtype=np.uint32)))
+    for tiles, offs, strides in lists:
+        rows = int(offs[-1]) // w + int(tiles["height"][-1])
+        out = torch.full((rows, w, 3), -1.0, dtype=torch.float32, device="cuda:0")
+        hip.render_device_async(scene, frame, tiles, offs, strides, True, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        for k in range(len(tiles)):
+            y0, th, r0 = int(tiles["y"][k]), int(tiles["height"][k]), int(offs[k]) // w
+            assert torch.equal(out[r0:r0 + th].view(torch.int32), full[y0:y0 + th].view(torch.int32)), (k, y0)
+    scene.close()
+
+
 def test_body_and_taper_slices_agree_with_the_reference_sample_order():
     """A frame of more than 2^20 pixels whose samples are cut into full-size items plus the
     tapered tail (4,4,2,2,1,1,1,1), against the same frame with every pixel's samples added in
