@@ -1542,6 +1542,20 @@ void trace_kernel(const TraceParams p) {
         n_samples++;
       }
     }
+    if constexpr (!ACCEL) {
+      // Out of work: a lane whose first path slot is finished takes its second slot's path into
+      // the first.  The wave's last paths then sit in slot 0 (unless a lane still has two), and
+      // everything a step does per slot - a pass of the matrix scan, the shading - is done once.
+      if (exhausted) {
+        const bool move = !P[0].alive && !P[0].has_item && P[1].alive;
+        if (move) {
+          P[0] = P[1];
+          P[1].alive = false;
+          P[1].has_item = false;
+          P[1].sample = P[1].sample_end = 0;
+        }
+      }
+    }
     bool any_alive = false;
 #pragma unroll
     for (int r = 0; r < RP; ++r) any_alive = any_alive || P[r].alive;
