@@ -887,6 +887,26 @@ __device__ __forceinline__ void mfma_list_always(Path (&P)[R], const MfmaChunk& 
   }
 }
 
+// The same spheres tested on the spot, every lane its own paths: what the list and the replay
+// would do with one entry per scanned path, without the entry (the reference's scenes have one
+// such sphere, the ground, which would otherwise be half of all entries).  The replay that
+// follows starts from the hits found here.
+__device__ __forceinline__ void mfma_test_always(Path (&P)[R], const MfmaChunk& m, uint32_t n_rows,
+                                                 uint32_t cn) {
+  for (uint32_t li = n_rows; li < cn; ++li) {
+    const float4 rec = m.geom[li];
+    const uint32_t world = m.index[li];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (P[r].alive && !P[r].degenerate) {
+        ReplayBounds rb = replay_bounds(P[r].closest, P[r].a);
+        candidate_hit(rec, world, mk(P[r].ox, P[r].oy, P[r].oz), mk(P[r].dx, P[r].dy, P[r].dz),
+                      P[r].a, rb, P[r].closest, P[r].best);
+      }
+    }
+  }
+}
+
 // One pass over the chunk's rows for one half of the wave's paths (path slot `half` of every
 // lane; b = mfma_prepare_half's columns).  Sixteen results per lane at a time, for 16 spheres x
 // 64 paths; thirty-two at a time (both halves) does not fit the register budget.
@@ -1626,7 +1646,7 @@ void trace_kernel(const TraceParams p) {
       } else if (!tail) {
         // one chunk: a half's columns are built right before its pass, so that only four
         // operands (16 VGPRs) are alive at a time
-        mfma_list_always(P, mc, n_in, n, wl, lane, clk);
+        mfma_test_always(P, mc, n_in, n);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           if (!mfma_half_scanned(P[r])) continue;
