@@ -1111,17 +1111,40 @@ __device__ __forceinline__ void tail_hit(Path (&P)[R], const SceneDev& sc, const
     const float ndx = f[7 * kWave], ndy = f[8 * kWave], ndz = f[9 * kWave];
     const float od = f[10 * kWave], thr = f[11 * kWave];
     ReplayBounds rb = replay_bounds(c, a);
-    for (uint32_t i = sub; i < sc.n_spheres; i += g) {
-      const float4 s = IN_LDS ? sph[i] : sc.trig[i];
-      if (!STRICT) {
-        // the same filter, with the same guarantee, as test_block's conservative form
-        const float kh = PERM ? sr2[i] : s.w;
-        const float hb = __builtin_fmaf(s.z, ndz, __builtin_fmaf(s.y, ndy, __builtin_fmaf(s.x, ndx, od)));
-        const float qh = __builtin_fmaf(s.z, oz, __builtin_fmaf(s.y, oy, __builtin_fmaf(s.x, ox, kh)));
-        if (__builtin_fmaf(hb, hb, qh) < thr) continue;
+    // Four spheres per trip, their records read before any is looked at: a step of the last
+    // paths is a chain of dependent instructions with nothing else on the SIMD to hide a read's
+    // latency behind, and one read per trip made the loop wait for LDS 31 times over.
+    constexpr int TU = 4;
+    const uint32_t last = sc.n_spheres - 1;   // n_spheres > 0 here: a path is alive
+    for (uint32_t i = sub; i < sc.n_spheres; i += TU * g) {
+      float4 s[TU];
+      float kh[TU];
+      uint32_t at[TU];
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        const uint32_t want = i + (uint32_t)u * g;
+        at[u] = want < last ? want : last;   // past the end: the last sphere again (harmless)
+        s[u] = IN_LDS ? sph[at[u]] : sc.trig[at[u]];
+        kh[u] = PERM ? sr2[at[u]] : s[u].w;
       }
-      const float4 geo = PERM ? s : IN_LDS ? make_float4(s.x, s.y, s.z, sr2[i]) : sc.geom[i];
-      candidate_hit(geo, PERM ? index[i] : i, mk(ox, oy, oz), mk(dx, dy, dz), a, rb, c, b);
+      bool pass[TU];
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        pass[u] = true;
+        if (!STRICT) {
+          // the same filter, with the same guarantee, as test_block's conservative form
+          const float hb = __builtin_fmaf(s[u].z, ndz, __builtin_fmaf(s[u].y, ndy, __builtin_fmaf(s[u].x, ndx, od)));
+          const float qh = __builtin_fmaf(s[u].z, oz, __builtin_fmaf(s[u].y, oy, __builtin_fmaf(s[u].x, ox, kh[u])));
+          pass[u] = !(__builtin_fmaf(hb, hb, qh) < thr);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TU; ++u) {
+        if (pass[u]) {
+          const float4 geo = PERM ? s[u] : IN_LDS ? make_float4(s[u].x, s[u].y, s[u].z, sr2[at[u]]) : sc.geom[at[u]];
+          candidate_hit(geo, PERM ? index[at[u]] : at[u], mk(ox, oy, oz), mk(dx, dy, dz), a, rb, c, b);
+        }
+      }
     }
   }
   // minimum over the lanes of each group (all 64 lanes take part; idle ones carry "no hit")
