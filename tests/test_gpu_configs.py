@@ -103,6 +103,65 @@ def test_10k_brute_force_full_size_frame_properties():
     scene.close()
 
 
+def test_headline_frame_at_its_own_size_and_sample_count():
+    """1920x1080 @ 100 spp, max_depth 50, 488 spheres (the configuration the metric is quoted on):
+    the frame twice (same bits), with the filter on the vector ALU and through the hierarchy (same
+    bits), as the eight shares of an 8-GPU run (same bits, same counters), and ten of its rows
+    with every pixel's samples added in the reference's order (within the association bound)."""
+    w, h, spp = 1920, 1080, 100
+    world = host.create_random_world(1, (-11, 11))
+    assert len(world.spheres) == 488
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
+    scene = hip.Scene(world.spheres, world.materials)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def whole(flags):
+        out = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+        frame = hip.make_frame(camera.m, w, h, spp, 50, 1, flags=flags)
+        hip.render_rows_device_async(scene, frame, 0, h, True, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return out, hip.get_stats()
+
+    full, st = whole(0)
+    assert st.samples == w * h * spp and st.slices == 50 and st.threads_per_workgroup == 1024
+    assert st.sphere_tests == st.rays * 488
+    again, st2 = whole(0)
+    assert torch.equal(again.view(torch.int32), full.view(torch.int32)) and st2.rays == st.rays
+    for flags in (abi.RT_FLAG_SCAN_VALU, abi.RT_FLAG_ACCEL):
+        other, sto = whole(flags)
+        assert torch.equal(other.view(torch.int32), full.view(torch.int32)), flags
+        assert sto.rays == st.rays
+    frame = hip.make_frame(camera.m, w, h, spp, 50, 1, flags=0)
+    plan = multi_gpu.RowPlan(w, h, 8)
+    stacked = torch.zeros((8, plan.rows_per_rank, w, 3), dtype=torch.float32, device="cuda:0")
+    rays = 0
+    for rank in range(8):
+        tiles, offs, strides = plan.tiles_for(rank)
+        hip.render_device_async(scene, frame, tiles, offs, strides, True, stacked[rank].data_ptr(), stream)
+        torch.cuda.synchronize()
+        rays += hip.get_stats().rays
+    assert rays == st.rays
+    row_map = torch.from_numpy(plan.frame_row_map()).to("cuda:0")
+    assert torch.equal(stacked.reshape(-1, w, 3).index_select(0, row_map).view(torch.int32),
+                       full.view(torch.int32))
+    # rows 500..509 as un-normalised sums: sliced (50 items of 2 samples) against sequential
+    sums = {}
+    for name, flags in (("sliced", 0), ("sequential", SEQ)):
+        out = torch.zeros((10, w, 3), dtype=torch.float32, device="cuda:0")
+        fr = hip.make_frame(camera.m, w, h, spp, 50, 1, flags=flags)
+        hip.render_rows_device_async(scene, fr, 500, 510, False, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        sums[name] = out.cpu().numpy().astype(np.float64)
+    err = np.abs(sums["sliced"] - sums["sequential"]) / np.maximum(np.abs(sums["sequential"]), 1.0)
+    assert err.max() <= 2 * spp * 2.0 ** -24, err.max()
+    resolved = np.sqrt(sums["sliced"].astype(np.float32) * np.float32(1.0 / spp))
+    resolved = np.where(resolved > np.float32(0.999), np.float32(0.999), resolved).astype(np.float32)
+    got = full[500:510].cpu().numpy()
+    ok = ~np.isnan(resolved)
+    assert np.array_equal(got[ok].view(np.uint32), resolved[ok].view(np.uint32))
+    scene.close()
+
+
 def test_4k_500spp_eight_row_shares_reassemble_to_the_whole_frame():
     """3840x2160 @ 500 spp (54 slices of 9 samples and a taper of 8): the frame rendered whole,
     then as the eight shares RowPlan deals to 8 GPUs, one after the other on this GPU through the
