@@ -250,6 +250,79 @@ __global__ __launch_bounds__(256) void k_rate(float* out, int iters, int seed) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// ---- do vector and matrix instructions share a SIMD's issue? ----------------------------------------
+// Per trip 8 independent MFMAs and/or 32 independent FMAs.  WHAT 0: the MFMAs only; 1: the FMAs
+// only; 2: both, interleaved, in every wave; 3: waves 0 and 2 of a workgroup (one per SIMD pair)
+// run the MFMAs, waves 1 and 3 the FMAs.  If the two kinds overlapped, 2 and 3 would take as long
+// as the slower of 0 and 1; if they share the issue, as long as both together.
+template <int WHAT>
+__global__ __launch_bounds__(256) void k_mix(float* out, int iters, int seed) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  h8 a, b;
+  for (int j = 0; j < 8; ++j) {
+    a[j] = (_Float16)(0.001f * (float)((lane + j + seed) & 15));
+    b[j] = (_Float16)(0.002f * (float)((lane * 3 + j + seed) & 7));
+  }
+  f4v c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
+  float f[8];
+  for (int j = 0; j < 8; ++j) f[j] = 0.001f * (float)(lane + j + seed);
+  const float m = 1.0001f, k = 0.0001f;
+  const bool do_m = WHAT == 0 || WHAT == 2 || (WHAT == 3 && (wave & 1) == 0);
+  const bool do_v = WHAT == 1 || WHAT == 2 || (WHAT == 3 && (wave & 1) == 1);
+  const int trips = WHAT == 3 ? 2 * iters : iters;   // each kind of wave does both waves' share
+  for (int it = 0; it < trips; ++it) {
+    if (do_m && do_v) {
+      asm volatile(
+          "v_mfma_f32_16x16x32_f16 %0, %16, %17, %0\n v_fma_f32 %8, %8, %18, %19\n v_fma_f32 %9, %9, %18, %19\n v_fma_f32 %10, %10, %18, %19\n v_fma_f32 %11, %11, %18, %19\n"
+          "v_mfma_f32_16x16x32_f16 %1, %16, %17, %1\n v_fma_f32 %12, %12, %18, %19\n v_fma_f32 %13, %13, %18, %19\n v_fma_f32 %14, %14, %18, %19\n v_fma_f32 %15, %15, %18, %19\n"
+          "v_mfma_f32_16x16x32_f16 %2, %16, %17, %2\n v_fma_f32 %8, %8, %18, %19\n v_fma_f32 %9, %9, %18, %19\n v_fma_f32 %10, %10, %18, %19\n v_fma_f32 %11, %11, %18, %19\n"
+          "v_mfma_f32_16x16x32_f16 %3, %16, %17, %3\n v_fma_f32 %12, %12, %18, %19\n v_fma_f32 %13, %13, %18, %19\n v_fma_f32 %14, %14, %18, %19\n v_fma_f32 %15, %15, %18, %19\n"
+          "v_mfma_f32_16x16x32_f16 %4, %16, %17, %4\n v_fma_f32 %8, %8, %18, %19\n v_fma_f32 %9, %9, %18, %19\n v_fma_f32 %10, %10, %18, %19\n v_fma_f32 %11, %11, %18, %19\n"
+          "v_mfma_f32_16x16x32_f16 %5, %16, %17, %5\n v_fma_f32 %12, %12, %18, %19\n v_fma_f32 %13, %13, %18, %19\n v_fma_f32 %14, %14, %18, %19\n v_fma_f32 %15, %15, %18, %19\n"
+          "v_mfma_f32_16x16x32_f16 %6, %16, %17, %6\n v_fma_f32 %8, %8, %18, %19\n v_fma_f32 %9, %9, %18, %19\n v_fma_f32 %10, %10, %18, %19\n v_fma_f32 %11, %11, %18, %19\n"
+          "v_mfma_f32_16x16x32_f16 %7, %16, %17, %7\n v_fma_f32 %12, %12, %18, %19\n v_fma_f32 %13, %13, %18, %19\n v_fma_f32 %14, %14, %18, %19\n v_fma_f32 %15, %15, %18, %19\n"
+          : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7),
+            "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
+          : "v"(a), "v"(b), "v"(m), "v"(k));
+    } else if (do_m) {
+      asm volatile(
+          "v_mfma_f32_16x16x32_f16 %0, %8, %9, %0\n v_mfma_f32_16x16x32_f16 %1, %8, %9, %1\n"
+          "v_mfma_f32_16x16x32_f16 %2, %8, %9, %2\n v_mfma_f32_16x16x32_f16 %3, %8, %9, %3\n"
+          "v_mfma_f32_16x16x32_f16 %4, %8, %9, %4\n v_mfma_f32_16x16x32_f16 %5, %8, %9, %5\n"
+          "v_mfma_f32_16x16x32_f16 %6, %8, %9, %6\n v_mfma_f32_16x16x32_f16 %7, %8, %9, %7\n"
+          : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7)
+          : "v"(a), "v"(b));
+    } else if (do_v) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        asm volatile(
+            "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+            "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+            : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])
+            : "v"(m), "v"(k));
+    }
+  }
+  float s = c0[0] + c1[1] + c2[2] + c3[3] + c4[0] + c5[1] + c6[2] + c7[3];
+  for (int j = 0; j < 8; ++j) s += f[j];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int WHAT>
+static float time_mix(int cus, int wgs_per_cu, float* d_out, int n_it) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const dim3 grid(cus * wgs_per_cu);
+  hipLaunchKernelGGL(k_mix<WHAT>, grid, dim3(256), 0, 0, d_out, 10, 1);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(k_mix<WHAT>, grid, dim3(256), 0, 0, d_out, n_it, 1);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms;
+}
+
 int main(int argc, char** argv) {
   int iters = argc > 1 ? atoi(argv[1]) : 40;
   if (argc > 2) g_thr_bias = (float)atof(argv[2]);
@@ -311,6 +384,24 @@ int main(int argc, char** argv) {
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dD));
   }
 
+
+  // ---- vector and matrix issue, alone and together ----
+  if (argc > 1 && !strcmp(argv[1], "mix")) {
+    float* d_out;
+    CK(hipMalloc(&d_out, (size_t)prop.multiProcessorCount * 8 * 256 * 4));
+    for (int wgs_per_cu = 1; wgs_per_cu <= 4; wgs_per_cu *= 2) {
+      const int n_it = 4000;
+      const float t0 = time_mix<0>(prop.multiProcessorCount, wgs_per_cu, d_out, n_it);
+      const float t1 = time_mix<1>(prop.multiProcessorCount, wgs_per_cu, d_out, n_it);
+      const float t2 = time_mix<2>(prop.multiProcessorCount, wgs_per_cu, d_out, n_it);
+      const float t3 = time_mix<3>(prop.multiProcessorCount, wgs_per_cu, d_out, n_it);
+      printf("%d wave(s)/SIMD, per trip 8 MFMA 16x16x32 f16 / 32 FMA f32: MFMA alone %.3f ms, FMA alone %.3f ms, "
+             "both in every wave %.3f ms, in alternate waves %.3f ms (sum %.3f, larger %.3f)\n",
+             wgs_per_cu, t0, t1, t2, t3, t0 + t1, t0 > t1 ? t0 : t1);
+    }
+    CK(hipFree(d_out));
+    return 0;
+  }
 
   // ---- the instruction's rate ----
   {
