@@ -186,6 +186,40 @@ def profiled_traffic(config, kernel):
             "%s (rocprofv3 --pmc, bytes per launch of an earlier run of this command%s)" % (rel, commit))
 
 
+def profiled_issue_bound(config, kernel, kernel_ms):
+    """What share of the SIMDs' cycles the kernel's vector and matrix instructions need just to
+    issue: instruction counts per launch from the committed rocprofv3 PMC passes of this command
+    (SQ_INSTS_VALU, SQ_INSTS_MFMA), priced at what a SIMD was measured to issue them at with four
+    waves (2.2 cycles a vector instruction, 21.6 a v_mfma_f32_16x16x32_f16, no overlap between the
+    two: tools/ubench), against this run's kernel time at the nominal clock.  The lower figure
+    takes SQ_INSTS_VALU to include the matrix instructions.  None without a profile."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "round2", config + "_pmc_per_launch.csv")
+    if not os.path.exists(path) or not kernel_ms > 0:
+        return None
+    count = {}
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["kernel"] == kernel and row["counter"] in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA"):
+                count[row["counter"]] = float(row["value_per_launch"])
+    if len(count) != 2:
+        return None
+    simd_cycles = kernel_ms * 1e-3 * 2.4e9 * 256 * 4
+    mfma = count["SQ_INSTS_MFMA"] * 21.6
+    return {
+        "valu_insts_per_launch": count["SQ_INSTS_VALU"],
+        "mfma_insts_per_launch": count["SQ_INSTS_MFMA"],
+        "cycles_per_valu": 2.2,
+        "cycles_per_mfma": 21.6,
+        "frac_low": round(((count["SQ_INSTS_VALU"] - count["SQ_INSTS_MFMA"]) * 2.2 + mfma) / simd_cycles, 4),
+        "frac_high": round((count["SQ_INSTS_VALU"] * 2.2 + mfma) / simd_cycles, 4),
+        "note": "share of all SIMD-cycles (nominal clock) that issuing the launch's vector and matrix "
+                "instructions takes; the two kinds do not overlap on a SIMD "
+                "(profiles/round2/ubench_mfma_valu_mix.txt)",
+        "source": os.path.relpath(path, ROOT),
+    }
+
+
 def valu_roofline(achieved, traffic, traffic_source, kernel_name, kernel_ms, kernel_ms_source, st):
     """Roofline of a launch whose filter ran on the vector ALU, against the FP32 VALU peak."""
     return {
@@ -393,6 +427,7 @@ def main():
                              "terms of the discriminant's bilinear form, three split-f16 products "
                              "each, and the threshold) x 2 flop; frac is also the share of time "
                              "the matrix pipe is busy at the nominal clock",
+                "issue_bound": profiled_issue_bound(args.config, kernel_name, kernel_ms) if world == 1 else None,
                 "fp32_form": {
                     "flop_per_ray_sphere_test": FLOP_PER_TEST,
                     "achieved": round(achieved, 3),
