@@ -1513,7 +1513,7 @@ void trace_kernel(const TraceParams p) {
                                       (size_t)kSlots * sizeof(unsigned long long));
   wl.counter = reinterpret_cast<uint32_t*>(wave_lds + kWaveListBytes);
   wl.count = 0;
-  wl.counter[1] = 0u;
+  if (!ACCEL) wl.counter[1] = 0u;   // (the traversal keeps no lists: its LDS holds stacks and the hierarchy)
   wl.redo_from = kNone;
 
   if (!MULTI && !ACCEL) {
