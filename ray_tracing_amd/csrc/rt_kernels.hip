@@ -1464,7 +1464,7 @@ __device__ __forceinline__ void write_item(const Path& P, const TraceParams& p) 
   o[0] = r; o[1] = g; o[2] = b;
 }
 
-__device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
+[[maybe_unused]] __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
   unsigned long long s = v;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
@@ -1559,7 +1559,7 @@ void trace_kernel(const TraceParams p) {
   }
   uint32_t grab_next = 0, grab_end = 0;
   bool exhausted = false;
-  uint32_t n_rays = 0, n_samples = 0;
+  unsigned long long n_rays = 0, n_samples = 0;   // of the wave (wave-uniform)
   uint32_t bvh_interior = 0, bvh_tests = 0;   // diagnostic build: nodes opened, spheres tested
   PhaseClock clk = {};
 #ifdef RT_DIAG_PHASES
@@ -1579,10 +1579,12 @@ void trace_kernel(const TraceParams p) {
       }
       const uint32_t item = wave_fetch(need, grab_next, grab_end, exhausted, p, lane);
       if (need && item != kNone) setup_item(P[r], item, p);
-      if (!P[r].alive && P[r].has_item && P[r].sample < P[r].sample_end) {
+      const bool begin = !P[r].alive && P[r].has_item && P[r].sample < P[r].sample_end;
+      // (counted for the wave on the scalar unit: no register per lane, no vector instruction)
+      n_samples += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(begin));
+      if (begin) {
         start_sample<MFMA>(P[r], p);
         if (MFMA) mfma_guard(P[r], p.scene.mfma_scale);
-        n_samples++;
       }
     }
     if constexpr (!ACCEL) {
@@ -1724,8 +1726,8 @@ void trace_kernel(const TraceParams p) {
     RT_MARK("shade");
 #pragma unroll
     for (int r = 0; r < RP; ++r) {
+      n_rays += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(P[r].alive));
       if (P[r].alive) {
-        n_rays++;
         const V3 o = mk(P[r].ox, P[r].oy, P[r].oz), d = mk(P[r].dx, P[r].dy, P[r].dz);
         bool ended;
         V3 radiance = mk(0.0f, 0.0f, 0.0f);
@@ -1805,11 +1807,9 @@ void trace_kernel(const TraceParams p) {
     }
   }
 #endif
-  const unsigned long long rays = wave_sum(n_rays);
-  const unsigned long long samples = wave_sum(n_samples);
   if (lane == 0) {
-    atomicAdd(&p.counters->rays, rays);
-    atomicAdd(&p.counters->samples, samples);
+    atomicAdd(&p.counters->rays, n_rays);
+    atomicAdd(&p.counters->samples, n_samples);
   }
 }
 
