@@ -112,45 +112,71 @@ void ro_mat4_perspective_rh(float fov_y_radians, float aspect, float z_near, flo
   out[14] = r * z_near;
 }
 
-/* General 4x4 inverse by cofactors (what glam's Mat4::inverse computes; glam's SSE2 path
- * orders the products differently, an ulp-level effect).  Call sites src/main.rs:65-66.
- * Returns 0 if the matrix is singular. */
+/* glam 0.21.2 Mat4::inverse, scalar implementation, operation for operation; call sites
+ * src/main.rs:65-66.  glam is not under /root/reference (Cargo.toml:10, Cargo.lock:277-279); this
+ * restates the crate's published scalar algorithm (the cofactor scheme it shares with GLM's
+ * compute_inverse): eighteen 2x2 sub-determinants `coef`, four cofactor columns
+ * inv_k = v_a * fac_x - v_b * fac_y + v_c * fac_z evaluated left to right, signs applied by a
+ * multiplication with (+1, -1, +1, -1) / (-1, +1, -1, +1), the determinant as the dot product of
+ * the first column with the first ROW of the cofactor matrix summed x + y + z + w left to right,
+ * and a final multiplication of every entry by 1 / det.  mCR below is column C, row R, as in glam.
+ * The x86-64 build of the crate takes its SSE2 path, which forms the same products and sums but
+ * adds the determinant's four terms as (x + z) + (y + w): not pinned here (an ulp-level effect).
+ * Returns 0 if the matrix is singular (glam asserts instead). */
 int ro_mat4_inverse(const float m[16], float out[16]) {
-  float a00 = m[0], a01 = m[1], a02 = m[2], a03 = m[3];
-  float a10 = m[4], a11 = m[5], a12 = m[6], a13 = m[7];
-  float a20 = m[8], a21 = m[9], a22 = m[10], a23 = m[11];
-  float a30 = m[12], a31 = m[13], a32 = m[14], a33 = m[15];
-  float b00 = a00 * a11 - a01 * a10;
-  float b01 = a00 * a12 - a02 * a10;
-  float b02 = a00 * a13 - a03 * a10;
-  float b03 = a01 * a12 - a02 * a11;
-  float b04 = a01 * a13 - a03 * a11;
-  float b05 = a02 * a13 - a03 * a12;
-  float b06 = a20 * a31 - a21 * a30;
-  float b07 = a20 * a32 - a22 * a30;
-  float b08 = a20 * a33 - a23 * a30;
-  float b09 = a21 * a32 - a22 * a31;
-  float b10 = a21 * a33 - a23 * a31;
-  float b11 = a22 * a33 - a23 * a32;
-  float det = b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06;
-  if (det == 0.0f) return 0;
-  float inv = 1.0f / det;
-  out[0] = (a11 * b11 - a12 * b10 + a13 * b09) * inv;
-  out[1] = (a02 * b10 - a01 * b11 - a03 * b09) * inv;
-  out[2] = (a31 * b05 - a32 * b04 + a33 * b03) * inv;
-  out[3] = (a22 * b04 - a21 * b05 - a23 * b03) * inv;
-  out[4] = (a12 * b08 - a10 * b11 - a13 * b07) * inv;
-  out[5] = (a00 * b11 - a02 * b08 + a03 * b07) * inv;
-  out[6] = (a32 * b02 - a30 * b05 - a33 * b01) * inv;
-  out[7] = (a20 * b05 - a22 * b02 + a23 * b01) * inv;
-  out[8] = (a10 * b10 - a11 * b08 + a13 * b06) * inv;
-  out[9] = (a01 * b08 - a00 * b10 - a03 * b06) * inv;
-  out[10] = (a30 * b04 - a31 * b02 + a33 * b00) * inv;
-  out[11] = (a21 * b02 - a20 * b04 - a23 * b00) * inv;
-  out[12] = (a11 * b07 - a10 * b09 - a12 * b06) * inv;
-  out[13] = (a00 * b09 - a01 * b07 + a02 * b06) * inv;
-  out[14] = (a31 * b01 - a30 * b03 - a32 * b00) * inv;
-  out[15] = (a20 * b03 - a21 * b01 + a22 * b00) * inv;
+  const float m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3];
+  const float m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
+  const float m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11];
+  const float m30 = m[12], m31 = m[13], m32 = m[14], m33 = m[15];
+
+  const float coef00 = m22 * m33 - m32 * m23;
+  const float coef02 = m12 * m33 - m32 * m13;
+  const float coef03 = m12 * m23 - m22 * m13;
+  const float coef04 = m21 * m33 - m31 * m23;
+  const float coef06 = m11 * m33 - m31 * m13;
+  const float coef07 = m11 * m23 - m21 * m13;
+  const float coef08 = m21 * m32 - m31 * m22;
+  const float coef10 = m11 * m32 - m31 * m12;
+  const float coef11 = m11 * m22 - m21 * m12;
+  const float coef12 = m20 * m33 - m30 * m23;
+  const float coef14 = m10 * m33 - m30 * m13;
+  const float coef15 = m10 * m23 - m20 * m13;
+  const float coef16 = m20 * m32 - m30 * m22;
+  const float coef18 = m10 * m32 - m30 * m12;
+  const float coef19 = m10 * m22 - m20 * m12;
+  const float coef20 = m20 * m31 - m30 * m21;
+  const float coef22 = m10 * m31 - m30 * m11;
+  const float coef23 = m10 * m21 - m20 * m11;
+
+  const float fac0[4] = {coef00, coef00, coef02, coef03};
+  const float fac1[4] = {coef04, coef04, coef06, coef07};
+  const float fac2[4] = {coef08, coef08, coef10, coef11};
+  const float fac3[4] = {coef12, coef12, coef14, coef15};
+  const float fac4[4] = {coef16, coef16, coef18, coef19};
+  const float fac5[4] = {coef20, coef20, coef22, coef23};
+  const float vec0[4] = {m10, m00, m00, m00};
+  const float vec1[4] = {m11, m01, m01, m01};
+  const float vec2[4] = {m12, m02, m02, m02};
+  const float vec3[4] = {m13, m03, m03, m03};
+  const float sign_a[4] = {1.0f, -1.0f, 1.0f, -1.0f};
+  const float sign_b[4] = {-1.0f, 1.0f, -1.0f, 1.0f};
+
+  float inv[16];   /* the cofactor matrix, column-major */
+  for (int i = 0; i < 4; ++i) {
+    const float inv0 = (vec1[i] * fac0[i] - vec2[i] * fac1[i]) + vec3[i] * fac2[i];
+    const float inv1 = (vec0[i] * fac0[i] - vec2[i] * fac3[i]) + vec3[i] * fac4[i];
+    const float inv2 = (vec0[i] * fac1[i] - vec1[i] * fac3[i]) + vec3[i] * fac5[i];
+    const float inv3 = (vec0[i] * fac2[i] - vec1[i] * fac4[i]) + vec2[i] * fac5[i];
+    inv[i] = inv0 * sign_a[i];
+    inv[4 + i] = inv1 * sign_b[i];
+    inv[8 + i] = inv2 * sign_a[i];
+    inv[12 + i] = inv3 * sign_b[i];
+  }
+  /* x_axis * (first row of the cofactor matrix), summed left to right */
+  const float dot1 = ((m00 * inv[0] + m01 * inv[4]) + m02 * inv[8]) + m03 * inv[12];
+  if (dot1 == 0.0f) return 0;
+  const float rcp_det = 1.0f / dot1;
+  for (int i = 0; i < 16; ++i) out[i] = inv[i] * rcp_det;
   return 1;
 }
 

@@ -253,7 +253,7 @@ void mfma_row(const rt_sphere& sp, double scale, uint16_t* row) {
     row[18 + t] = f16_bits(lo);
   }
   // k with the sphere side's slack taken off, in two parts that do not add up to more than k
-  const double k = c2 - r2 - std::ldexp(c2, -17) - std::ldexp(r2, -18) - std::ldexp(c2 + c1, -21);
+  const double k = c2 - r2 - std::ldexp(c2, -16) - std::ldexp(r2, -17) - std::ldexp(c2 + c1, -21);
   _Float16 kh = (_Float16)k;
   _Float16 kl = (_Float16)(k - (double)kh);
   while ((double)kh + (double)kl > k) {
@@ -482,12 +482,16 @@ int ensure_bvh(const rt_scene* s) {
   return RT_OK;
 }
 
-// Launch-geometry queries do not change for the life of the process; asking once per kernel
-// variant keeps the call path of a frame down to its launches.
+// Launch-geometry queries do not change for the life of the process; asking once per device and
+// kernel variant keeps the call path of a frame down to its launches.  (Per device: the matrix
+// kernel's query also raises that kernel's dynamic-LDS limit, which is a per-device attribute.)
 int blocks_per_cu(bool strict, bool multi, bool accel, bool mfma, size_t lds, int* out) {
   struct Entry { bool valid; size_t lds; int per_cu; };
-  static Entry cache[16] = {};
-  Entry& e = cache[(strict ? 1 : 0) | (multi ? 2 : 0) | (accel ? 4 : 0) | (mfma ? 8 : 0)];
+  static std::vector<Entry> cache;
+  const size_t at = (size_t)ctx().device * 16 +
+                    ((strict ? 1 : 0) | (multi ? 2 : 0) | (accel ? 4 : 0) | (mfma ? 8 : 0));
+  if (cache.size() <= at) cache.resize(at + 1, Entry{false, 0, 0});
+  Entry& e = cache[at];
   if (!e.valid || e.lds != lds) {
     int per_cu = 0;
     if (mfma) RT_HIP(rt::trace_max_blocks_per_cu_mfma(multi, lds, &per_cu));

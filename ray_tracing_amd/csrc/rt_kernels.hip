@@ -734,17 +734,31 @@ __device__ __forceinline__ void scan_chunk(Path (&P)[R], const float4* sph, cons
 //   + u C^2                             rounding of the ray's quadratic features
 //   + 28u (C^2 + C O + r^2 / 2)         the halves: host side rounded to nearest (4u), ray side both
 //                                       truncated (16u), lo.lo dropped (8u)
-//   + 16u (C^2 + C O + (r^2 + O^2) / 2) accumulation inside the instruction: four times the worst
-//                                       case measured over 8e5 products with heavy cancellation
-//                                       (3.9u of the sum of magnitudes, tools/ubench/mfma_scan.hip);
-//                                       f16 subnormals are honoured by the instruction (same probe)
+//   + 62u (C^2 + C O + (r^2 + O^2) / 2) accumulation inside the instruction, for ANY order of
+//                                       summation.  The 32 products (f16 x f16: exact in f32) sum
+//                                       to at most M = C^2 + C O + (r^2 + O^2) / 2 in magnitude
+//                                       (1/2 (|cx nx| + |cy ny| + |cz nz|)^2 <= C^2 / 2, |c.p| <=
+//                                       C O, |k| / 2, |p|^2 / 2).  ASSUMED of the pipe, whose
+//                                       internal order and rounding are not documented: every one
+//                                       of its 31 additions returns the exact sum of its operands
+//                                       to within 2u relative, which holds for round-to-nearest
+//                                       (u), for truncation (2u), for products aligned to the
+//                                       largest one and cut to 24 bits or more, and for any wider
+//                                       accumulator; then the total is within 31 * 2u * M whatever
+//                                       the order.  Measured (tools/ubench/mfma_scan.hip, 8e5
+//                                       products with heavy cancellation): 3.9u M at worst, and
+//                                       f16 subnormals are honoured by the instruction
 //   + 4u (C^2 + r^2)                    k's two parts
 //   + u O^2                             the threshold's three parts
 //   + 2^-21 max(C^2, C) + 2^-22 (1 + O) subnormal quanta (2^-25) of lo parts times the other side
-// i.e. below 90u C^2 + 64u O^2 + 26u r^2 plus the last line, on top of the reference's 22u / 22u / 11u.  The slack taken off is
-//     sphere side (k, host): 2^-17 C^2 + 2^-18 r^2 + 2^-21 (C^2 + C)          (128u + 8u, 64u)
-//     ray side (threshold):  (2^-17 + 2^-23) O^2 + 1.5 * 2^-22               (128u)
-// which covers the sum of both with room to spare.  A false positive costs one exact replay.
+// With C O <= (C^2 + O^2) / 2 that is below 158.5u C^2 + 110u O^2 + 49u r^2 plus the last line, on
+// top of the reference's 22u / 22u / 11u: 180.5u C^2 + 132u O^2 + 60u r^2 in all.  The slack taken
+// off is
+//     sphere side (k, host): 2^-16 C^2 + 2^-17 r^2 + 2^-21 (C^2 + C)          (256u + 8u, 128u)
+//     ray side (threshold):  (2^-16 + 2^-23) O^2 + 1.5 * 2^-22               (256u + 2u)
+// which covers the sum with more than 80u of each to spare.  A false positive costs one exact
+// replay, and the slack is a band 2^-16 of the discriminant's scale wide around the silhouette:
+// doubling it from 2^-17 changed the number of candidates per ray in the fifth digit.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 
@@ -798,8 +812,8 @@ __device__ __forceinline__ void mfma_ray_column(const Path& P, bool ok, float sc
                         nx * ny, nx * nz, ny * nz, px, py, pz};
     const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
     const float pp = __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px));
-    // (2^-17 + 2^-23) O^2 + 1.5 * 2^-22 off the threshold
-    const float thr = 0.5f * pp - __builtin_fmaf(oo, 7.748603820800781e-06f, 3.5762786865234375e-07f);
+    // (2^-16 + 2^-23) O^2 + 1.5 * 2^-22 off the threshold
+    const float thr = 0.5f * pp - __builtin_fmaf(oo, 1.5377998352050781e-05f, 3.5762786865234375e-07f);
     const uint32_t h01 = pk_bits(F[0], F[1]), h23 = pk_bits(F[2], F[3]), h45 = pk_bits(F[4], F[5]),
                    h67 = pk_bits(F[6], F[7]), h8x = pk_bits(F[8], 0.0f);
     // what the hi halves leave (each subtraction is exact)
@@ -1838,8 +1852,10 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
     const uint32_t count = p.total_pixels - first < kReducePixels ? p.total_pixels - first : kReducePixels;
     // Pixels that follow each other in the output (the rule inside a tile row) form one
     // contiguous block of count * run floats: copied 16 bytes per thread when it is so aligned.
+    // (every pixel of the group is checked: a caller's own tile offsets need not be monotone)
     const float* block = p.partial + where[0] * run;
-    const bool contiguous = where[count - 1] - where[0] == count - 1 &&
+    const bool in_place = threadIdx.x >= count || where[threadIdx.x] == where[0] + threadIdx.x;
+    const bool contiguous = __syncthreads_and(in_place ? 1 : 0) != 0 &&
                             (reinterpret_cast<uintptr_t>(block) & 15u) == 0 && ((count * run) & 3u) == 0;
     if (contiguous) {
       const float4* src4 = reinterpret_cast<const float4*>(block);

@@ -56,39 +56,40 @@ Mat4 perspective_rh(float fov_y_radians, float aspect_ratio, float z_near, float
   return m;
 }
 
-// Mat4::inverse: cofactor expansion over 2x2 sub-determinants
+// Mat4::inverse as glam 0.21.2's scalar implementation writes it (call sites src/main.rs:65-66):
+// eighteen 2x2 sub-determinants, four cofactor columns each evaluated as a * f - b * g + c * h
+// from left to right, the signs applied by a multiplication, the determinant as the first column
+// times the first row of the cofactors summed left to right, and every entry times 1 / det.
+// c[4 * C + R] is column C, row R.  (The crate's SSE2 path adds the determinant's four terms in
+// another order; that build is not reproduced here.)
 Mat4 inverse(const Mat4& in) {
   const float* m = in.c;
-  const float a00 = m[0], a01 = m[1], a02 = m[2], a03 = m[3];
-  const float a10 = m[4], a11 = m[5], a12 = m[6], a13 = m[7];
-  const float a20 = m[8], a21 = m[9], a22 = m[10], a23 = m[11];
-  const float a30 = m[12], a31 = m[13], a32 = m[14], a33 = m[15];
-  const float b00 = a00 * a11 - a01 * a10, b01 = a00 * a12 - a02 * a10;
-  const float b02 = a00 * a13 - a03 * a10, b03 = a01 * a12 - a02 * a11;
-  const float b04 = a01 * a13 - a03 * a11, b05 = a02 * a13 - a03 * a12;
-  const float b06 = a20 * a31 - a21 * a30, b07 = a20 * a32 - a22 * a30;
-  const float b08 = a20 * a33 - a23 * a30, b09 = a21 * a32 - a22 * a31;
-  const float b10 = a21 * a33 - a23 * a31, b11 = a22 * a33 - a23 * a32;
-  const float det = b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06;
+  // sub[k] = m[a] * m[b] - m[c] * m[d] for the index quadruples below, in glam's order
+  static const int kSub[18][4] = {
+      {10, 15, 14, 11}, {6, 15, 14, 7}, {6, 11, 10, 7},   // coef00, 02, 03
+      {9, 15, 13, 11},  {5, 15, 13, 7}, {5, 11, 9, 7},    // coef04, 06, 07
+      {9, 14, 13, 10},  {5, 14, 13, 6}, {5, 10, 9, 6},    // coef08, 10, 11
+      {8, 15, 12, 11},  {4, 15, 12, 7}, {4, 11, 8, 7},    // coef12, 14, 15
+      {8, 14, 12, 10},  {4, 14, 12, 6}, {4, 10, 8, 6},    // coef16, 18, 19
+      {8, 13, 12, 9},   {4, 13, 12, 5}, {4, 9, 8, 5}};    // coef20, 22, 23
+  float sub[18];
+  for (int k = 0; k < 18; ++k) sub[k] = m[kSub[k][0]] * m[kSub[k][1]] - m[kSub[k][2]] * m[kSub[k][3]];
+  // fac_g = (first, first, second, third) of group g; vec_r = (m[4 + r], m[r], m[r], m[r])
+  Mat4 cof;
+  for (int i = 0; i < 4; ++i) {
+    const auto fac = [&](int g) { return sub[3 * g + (i == 0 ? 0 : i - 1)]; };
+    const auto vec = [&](int r) { return i == 0 ? m[4 + r] : m[r]; };
+    const float sa = (i & 1) ? -1.0f : 1.0f, sb = -sa;
+    cof.c[i] = ((vec(1) * fac(0) - vec(2) * fac(1)) + vec(3) * fac(2)) * sa;
+    cof.c[4 + i] = ((vec(0) * fac(0) - vec(2) * fac(3)) + vec(3) * fac(4)) * sb;
+    cof.c[8 + i] = ((vec(0) * fac(1) - vec(1) * fac(3)) + vec(3) * fac(5)) * sa;
+    cof.c[12 + i] = ((vec(0) * fac(2) - vec(1) * fac(4)) + vec(2) * fac(5)) * sb;
+  }
+  const float det = ((m[0] * cof.c[0] + m[1] * cof.c[4]) + m[2] * cof.c[8]) + m[3] * cof.c[12];
   if (det == 0.0f) throw std::runtime_error("Mat4::inverse: singular matrix");
-  const float inv = 1.0f / det;
+  const float rcp_det = 1.0f / det;
   Mat4 o;
-  o.c[0] = (a11 * b11 - a12 * b10 + a13 * b09) * inv;
-  o.c[1] = (a02 * b10 - a01 * b11 - a03 * b09) * inv;
-  o.c[2] = (a31 * b05 - a32 * b04 + a33 * b03) * inv;
-  o.c[3] = (a22 * b04 - a21 * b05 - a23 * b03) * inv;
-  o.c[4] = (a12 * b08 - a10 * b11 - a13 * b07) * inv;
-  o.c[5] = (a00 * b11 - a02 * b08 + a03 * b07) * inv;
-  o.c[6] = (a32 * b02 - a30 * b05 - a33 * b01) * inv;
-  o.c[7] = (a20 * b05 - a22 * b02 + a23 * b01) * inv;
-  o.c[8] = (a10 * b10 - a11 * b08 + a13 * b06) * inv;
-  o.c[9] = (a01 * b08 - a00 * b10 - a03 * b06) * inv;
-  o.c[10] = (a30 * b04 - a31 * b02 + a33 * b00) * inv;
-  o.c[11] = (a21 * b02 - a20 * b04 - a23 * b00) * inv;
-  o.c[12] = (a11 * b07 - a10 * b09 - a12 * b06) * inv;
-  o.c[13] = (a00 * b09 - a01 * b07 + a02 * b06) * inv;
-  o.c[14] = (a31 * b01 - a30 * b03 - a32 * b00) * inv;
-  o.c[15] = (a20 * b03 - a21 * b01 + a22 * b00) * inv;
+  for (int k = 0; k < 16; ++k) o.c[k] = cof.c[k] * rcp_det;
   return o;
 }
 

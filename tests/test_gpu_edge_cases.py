@@ -1,6 +1,7 @@
 """Shapes and sizes at the seams of the GPU path: one-pixel images, one sample, sphere counts on
 either side of the LDS chunk size, scenes with no or one sphere.  Every case is held to the
-oracle's bits (sequential sums) in the default, literal and hierarchy modes."""
+oracle's bits (sequential sums) with the matrix filter, the vector filter, the literal arithmetic
+and the hierarchy."""
 import numpy as np
 import pytest
 
@@ -10,7 +11,7 @@ from ray_tracing_amd import abi, hip
 pytestmark = pytest.mark.gpu
 
 SEQ = abi.RT_FLAG_SEQUENTIAL_SUM
-MODES = (SEQ, SEQ | abi.RT_FLAG_STRICT_FP, SEQ | abi.RT_FLAG_ACCEL)
+MODES = (SEQ, SEQ | abi.RT_FLAG_SCAN_VALU, SEQ | abi.RT_FLAG_STRICT_FP, SEQ | abi.RT_FLAG_ACCEL)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -50,7 +51,11 @@ def test_tile_shapes(tile):
     check(s, m, 33, 21, 2, tile=tile)
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 5, 1199, 1200, 1201, 2016, 2400, 2401, 4033])
+# 1200 spheres is the vector filter's chunk, 512 rows the matrix filter's (one of the four big
+# spheres kept first, the ground, has no row: 513 spheres are 512 rows and a second chunk that
+# holds nothing but the listed sphere)
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 511, 512, 513, 514, 1024, 1025, 1199, 1200, 1201, 1537,
+                               2016, 2400, 2401, 4033])
 def test_sphere_counts_around_the_lds_chunk(n):
     s, m = O.random_world(1, -33, 33)        # 4360 spheres to cut from
     keep = np.r_[len(s) - 4:len(s), 0:len(s) - 4][:n]   # the four big ones first

@@ -216,6 +216,55 @@ def test_mat4_inverse_round_trip():
         assert np.allclose(A @ I, np.eye(4), atol=2e-3 * max(1.0, np.abs(I).max()))
 
 
+def glam_scalar_inverse(a):
+    """glam 0.21.2's scalar Mat4::inverse in numpy f32, written from the crate's published
+    algorithm independently of the C restatement (call sites src/main.rs:65-66).  m[c][r]."""
+    m = a.astype(F32).reshape(4, 4)
+    d = lambda p, q, r, s: F32(F32(p * q) - F32(r * s))   # noqa: E731
+    c00 = d(m[2][2], m[3][3], m[3][2], m[2][3]); c02 = d(m[1][2], m[3][3], m[3][2], m[1][3])
+    c03 = d(m[1][2], m[2][3], m[2][2], m[1][3]); c04 = d(m[2][1], m[3][3], m[3][1], m[2][3])
+    c06 = d(m[1][1], m[3][3], m[3][1], m[1][3]); c07 = d(m[1][1], m[2][3], m[2][1], m[1][3])
+    c08 = d(m[2][1], m[3][2], m[3][1], m[2][2]); c10 = d(m[1][1], m[3][2], m[3][1], m[1][2])
+    c11 = d(m[1][1], m[2][2], m[2][1], m[1][2]); c12 = d(m[2][0], m[3][3], m[3][0], m[2][3])
+    c14 = d(m[1][0], m[3][3], m[3][0], m[1][3]); c15 = d(m[1][0], m[2][3], m[2][0], m[1][3])
+    c16 = d(m[2][0], m[3][2], m[3][0], m[2][2]); c18 = d(m[1][0], m[3][2], m[3][0], m[1][2])
+    c19 = d(m[1][0], m[2][2], m[2][0], m[1][2]); c20 = d(m[2][0], m[3][1], m[3][0], m[2][1])
+    c22 = d(m[1][0], m[3][1], m[3][0], m[1][1]); c23 = d(m[1][0], m[2][1], m[2][0], m[1][1])
+    fac = [np.array(v, dtype=F32) for v in (
+        (c00, c00, c02, c03), (c04, c04, c06, c07), (c08, c08, c10, c11),
+        (c12, c12, c14, c15), (c16, c16, c18, c19), (c20, c20, c22, c23))]
+    vec = [np.array((m[1][r], m[0][r], m[0][r], m[0][r]), dtype=F32) for r in range(4)]
+    sa = np.array((1, -1, 1, -1), dtype=F32)
+    inv0 = ((vec[1] * fac[0] - vec[2] * fac[1]) + vec[3] * fac[2]) * sa
+    inv1 = ((vec[0] * fac[0] - vec[2] * fac[3]) + vec[3] * fac[4]) * -sa
+    inv2 = ((vec[0] * fac[1] - vec[1] * fac[3]) + vec[3] * fac[5]) * sa
+    inv3 = ((vec[0] * fac[2] - vec[1] * fac[4]) + vec[2] * fac[5]) * -sa
+    cols = np.stack([inv0, inv1, inv2, inv3]).astype(F32)
+    dot0 = m[0] * cols[:, 0]
+    det = F32(F32(F32(dot0[0] + dot0[1]) + dot0[2]) + dot0[3])
+    return (cols * F32(F32(1.0) / det)).astype(F32).reshape(16)
+
+
+def test_mat4_inverse_is_glam_scalar_operation_for_operation():
+    """Bit for bit against the numpy restatement, on matrices whose entries make every rounding
+    count, and on the two matrices Camera::new inverts (src/main.rs:59-66)."""
+    L = O.lib()
+    rng = np.random.default_rng(11)
+    mats = [rng.uniform(-2, 2, size=16).astype(F32) for _ in range(200)]
+    view = (C.c_float * 16)()
+    L.ro_mat4_look_at_rh(O.vec3(13, 2, 3), O.vec3(0, 0, 0), O.vec3(0, 1, 0), view)
+    proj = (C.c_float * 16)()
+    L.ro_mat4_perspective_rh(float(F32(20.0) * (F32(math.pi) / F32(180.0))), float(F32(16 / 9)),
+                             0.1, 100.0, proj)
+    mats += [np.array(view[:], dtype=F32), np.array(proj[:], dtype=F32)]
+    for a in mats:
+        inv = np.zeros(16, dtype=F32)
+        assert L.ro_mat4_inverse(a.ctypes.data_as(C.POINTER(C.c_float)),
+                                 inv.ctypes.data_as(C.POINTER(C.c_float))) == 1
+        want = glam_scalar_inverse(a)
+        assert np.array_equal(inv.view(np.uint32), want.view(np.uint32))
+
+
 # ---- random helpers, src/main.rs:266-286 -----------------------------------------------------
 
 def test_random_in_unit_sphere_rejects_then_accepts():
