@@ -378,7 +378,7 @@ def main():
     if matrix:
         kernel_name = "rt::trace_kernel<false,%s,false,true>" % ("true" if n_spheres > 512 else "false")
     else:
-        kernel_name = "rt::trace_kernel<false,%s,false,false>" % ("true" if n_spheres > 1200 else "false")
+        kernel_name = "rt::trace_kernel<false,%s,false,false>" % ("true" if n_spheres > 1136 else "false")
     if rank == 0:
         traffic, traffic_source = (profiled_traffic(args.config, kernel_name) if world == 1
                                    else (None, "not reported for N > 1"))
@@ -463,7 +463,7 @@ def main():
             v_ms = hip.get_launch_ms(min(args.steps, 64))
             v_st = hip.get_stats()
             v_kernel_ms = float(v_ms.mean()) if len(v_ms) else float("nan")
-            v_name = "rt::trace_kernel<false,%s,false,false>" % ("true" if n_spheres > 1200 else "false")
+            v_name = "rt::trace_kernel<false,%s,false,false>" % ("true" if n_spheres > 1136 else "false")
             v_traffic, v_source = profiled_traffic(args.config, v_name)
             v_achieved = FLOP_PER_TEST * n_spheres * v_st.rays / (v_kernel_ms * 1e-3) * 1e-12
             line["valu_scan"] = {

@@ -87,8 +87,8 @@ struct LaunchSlot {
   hipStream_t stream = nullptr;
   bool bound = false;
   rt::Counters* counters = nullptr;       // device
-  float* partial = nullptr;               // device: per-slice sums (grow-only; fixed for the
-  size_t partial_cap = 0;                 // no-alloc slot), capacity in floats
+  float* ring = nullptr;                  // device: the waves' parked slice sums (grow-only;
+  size_t ring_cap = 0;                    // fixed for the no-alloc slot), capacity in floats
   uint64_t last_use = 0;
   rt_stats last = {};
   uint64_t launch_no = 0;                 // 1-based number of the slot's last launch; 0 = none
@@ -395,21 +395,20 @@ int check_frame(const rt_frame* f) {
 }
 
 // How one pixel's samples are cut into work items.  Slice k runs samples
-// [begin[k], begin[k+1]); its sum lands in plane k of a partial buffer and a second kernel adds
-// the planes in slice order.  Two reasons to cut:
+// [begin[k], begin[k+1]) in one lane; the wave that runs a pixel's slices adds their sums in slice
+// order and writes the pixel (merge_ready in rt_kernels.hip).  Two reasons to cut:
 //  * granularity: a path at max_depth 50 inside glass can cost 20x the average, and a lane
 //    runs its item to the end while the frame's last items drain, so items must be small where
-//    it matters.  The last eight slices are tapered down to single samples
-//    (.., B, B, 4, 4, 2, 2, 1, 1, 1, 1) and issued after all the full-size ones, so what
-//    drains last is small.
-//  * small images: fewer pixels than lanes.
+//    it matters.  The last eight slices of a long plan are tapered down to single samples
+//    (.., B, B, 4, 4, 2, 2, 1, 1, 1, 1).
+//  * small images (and a rank's share of a frame): fewer pixels than lanes.
 // The cut is a function of the FULL image and spp only, so a frame gives the same sums
 // whatever part of it a call renders and however many GPUs share it.
 // Writes begin[0..n] and returns n, the number of slices (at most rt::kMaxSlices).
-uint32_t plan_slices(const rt_frame& f, uint32_t* begin, uint32_t* body_slices) {
+uint32_t plan_slices(const rt_frame& f, uint32_t* begin) {
   const uint32_t spp = f.samples_per_pixel;
   uint32_t sizes[rt::kMaxSlices];
-  uint32_t n = 0, tail = 0;
+  uint32_t n = 0;
   if (f.flags & RT_FLAG_SEQUENTIAL_SUM) {
     sizes[n++] = spp;
   } else {
@@ -433,7 +432,6 @@ uint32_t plan_slices(const rt_frame& f, uint32_t* begin, uint32_t* body_slices) 
     }
     if (use_taper) {
       for (uint32_t t : taper) sizes[n++] = t;
-      tail = 8;
     }
     // small image: more, equal slices so that every lane has an item
     const uint64_t pixels = (uint64_t)f.image_width * f.image_height;
@@ -442,14 +440,12 @@ uint32_t plan_slices(const rt_frame& f, uint32_t* begin, uint32_t* body_slices) 
     if (want > rt::kMaxSlices) want = rt::kMaxSlices;
     if (want > n) {
       n = 0;
-      tail = 0;
       for (uint64_t k = 0; k < want; ++k)
         sizes[n++] = (uint32_t)(((k + 1) * spp) / want - (k * spp) / want);
     }
   }
   begin[0] = 0;
   for (uint32_t k = 0; k < n; ++k) begin[k + 1] = begin[k] + sizes[k];
-  *body_slices = n - tail;
   return n;
 }
 
@@ -531,10 +527,13 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   p.seed_a = rt_rng_seed_a(frame->seed);
   p.seed_b = rt_rng_seed_b(frame->seed);
   uint32_t slice_begin[rt::kMaxSlices + 1];
-  p.slices = plan_slices(*frame, slice_begin, &p.body_slices);
+  p.slices = plan_slices(*frame, slice_begin);
   for (uint32_t k = 0; k <= p.slices; ++k) p.slice_begin[k] = sample_begin + slice_begin[k];
-  p.body_div = rt::make_divider(p.body_slices);
-  p.tail_div = rt::make_divider(p.slices - p.body_slices);
+  p.slices_div = rt::make_divider(p.slices);
+  // a wave reserves whole pixels: 64 items when a pixel is one item, otherwise as many pixels as
+  // make up to 100 items (1 to kGrabPixelsMax)
+  p.grab_pixels = p.slices == 1 ? rt::kItemsPerGrab
+                                : std::min(rt::kGrabPixelsMax, std::max(1u, 100u / p.slices));
   p.n_tiles = (uint32_t)n_tiles;
   uint64_t total_pixels = 0;
   for (size_t i = 0; i < n_tiles; ++i) total_pixels += (uint64_t)tiles[i].w * tiles[i].h;
@@ -563,18 +562,10 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   }
   p.scene = scene->dev;
 
-  const size_t partial_need = p.slices > 1 ? (size_t)out_pixels * 3 * p.slices : 0;
   LaunchSlot* slot = nullptr;
   if (no_alloc) {
     slot = &ctx().noalloc_slot;
     if (n_tiles != 1) return fail(RT_ERR_INVALID_ARGUMENT, "one tile per call");
-    if (partial_need > slot->partial_cap)
-      return fail(RT_ERR_LIMIT,
-                  "%llu pixels x %u sample slices need %zu bytes of partial sums; the fixed buffer "
-                  "of this entry point holds %zu (render fewer rows per call, or set "
-                  "RT_FLAG_SEQUENTIAL_SUM, which needs none)",
-                  (unsigned long long)out_pixels, p.slices, partial_need * sizeof(float),
-                  slot->partial_cap * sizeof(float));
     slot->stream = stream;
     slot->last_use = ctx().launches + 1;
   } else if (int rc = acquire_slot(stream, &slot)) {
@@ -624,31 +615,23 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
     p.tiles = ctx().tiles;
   }
 
-  rt::ReduceParams rp;
-  memset(&rp, 0, sizeof rp);
-  rp.out = d_out;
-  rp.out_pixels = out_pixels;
-  rp.n_tiles = p.n_tiles;
-  rp.total_pixels = p.total_pixels;
-  rp.tile0 = p.tile0;
-  rp.tiles = p.tiles;
-  if (row_blocks) {   // (the reduce kernel keeps the list; only the trace kernel takes the rule)
+  rt::ZeroParams zp;
+  memset(&zp, 0, sizeof zp);
+  zp.out = d_out;
+  zp.n_tiles = p.n_tiles;
+  zp.total_pixels = p.total_pixels;
+  zp.tile0 = p.tile0;
+  zp.tiles = p.tiles;
+  if (row_blocks) {   // the trace kernel takes the rule instead of the list
     p.n_tiles = 1;
     p.tile0 = tiles[0];
   }
-  rp.resolve = resolve;
-  rp.accumulate = accumulate ? 1 : 0;
-  rp.inv_spp = p.inv_spp;
 
   if (frame->max_depth == 0) {
     // shoot_ray(ray, 0) is black (src/main.rs:192-194): every sum is 0 and nothing is traced.
     // Only the pixels the tiles cover are written, like in every other case (the gaps of a
     // strided output may belong to another call); adding zero to a running sum changes nothing.
-    if (!accumulate) {
-      rp.partial = nullptr;
-      rp.slices = 0;
-      RT_HIP(rt::launch_reduce(rp, stream));
-    }
+    if (!accumulate) RT_HIP(rt::launch_zero(zp, stream));
     slot->last = {};
     slot->last.samples = total_pixels * frame->samples_per_pixel;
     slot->launch_no = 0;
@@ -656,23 +639,9 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
     return RT_OK;
   }
 
-  float* trace_out = d_out;
-  if (p.slices > 1) {
-    if (partial_need > slot->partial_cap) {   // never true for the fixed slot (checked above)
-      RT_HIP(hipStreamSynchronize(stream));   // the slot's earlier launches read the old buffer
-      if (slot->partial) RT_HIP(hipFree(slot->partial));
-      slot->partial = nullptr;
-      slot->partial_cap = 0;
-      RT_HIP(hipMalloc((void**)&slot->partial, partial_need * sizeof(float)));
-      slot->partial_cap = partial_need;
-    }
-    trace_out = slot->partial;
-    p.resolve = 0;
-  } else {
-    p.resolve = resolve;
-    p.accumulate = accumulate ? 1 : 0;
-  }
-  p.out = trace_out;
+  p.resolve = resolve;
+  p.accumulate = accumulate ? 1 : 0;
+  p.out = d_out;
 
   bool bvh_in_lds = false;
   p.bvh_stack = scene->bvh_depth ? scene->bvh_depth : 1;
@@ -685,7 +654,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
                     cam2 < 536870912.0;   // 2^29: a quarter of the filter's limit on |o|^2
   const size_t lds = mfma ? rt::trace_lds_bytes_mfma(rt::kThreadsMfma)
                           : rt::trace_lds_bytes(scene->dev.n_spheres, accel, scene->dev.bvh_info.n_nodes,
-                                                p.bvh_stack, &bvh_in_lds);
+                                                p.bvh_stack, &bvh_in_lds, &p.slot_table_offset);
   p.bvh_in_lds = bvh_in_lds ? 1 : 0;
   const bool multi = scene->dev.n_spheres > (mfma ? rt::kMfmaChunk : rt::kChunkSpheres);
   int per_cu = 0;
@@ -699,20 +668,41 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
   if (blocks < 1) blocks = 1;
 
-  // the counters must start at zero; the planes need no clearing (every covered pixel of every
-  // plane is written by the trace kernel before the reduce kernel reads it)
+  // Sliced samples: every wave of the launch parks the slice sums of its open pixels in a ring
+  // of its own, ring_slots pixels long (all of kRingSlots when the memory is the library's to
+  // size; as many as fit for the entry point that may not allocate).
+  if (p.slices > 1) {
+    const size_t waves = (size_t)blocks * (threads / rt::kWave);
+    const size_t per_slot = (size_t)3 * p.slices;               // floats
+    p.ring_slots = rt::kRingSlots;
+    if (no_alloc) {
+      const size_t fit = slot->ring_cap / (waves * per_slot);
+      if (fit < p.ring_slots) p.ring_slots = (uint32_t)fit;
+      if (p.ring_slots < 1)
+        return fail(RT_ERR_LIMIT, "%zu waves x %u sample slices do not fit the fixed buffer", waves,
+                    p.slices);
+    }
+    if (p.grab_pixels > p.ring_slots) p.grab_pixels = p.ring_slots;
+    const size_t need = waves * p.ring_slots * per_slot;
+    if (need > slot->ring_cap) {              // never true for the fixed slot
+      RT_HIP(hipStreamSynchronize(stream));   // the slot's earlier launches use the old buffer
+      if (slot->ring) RT_HIP(hipFree(slot->ring));
+      slot->ring = nullptr;
+      slot->ring_cap = 0;
+      RT_HIP(hipMalloc((void**)&slot->ring, need * sizeof(float)));
+      slot->ring_cap = need;
+    }
+    p.ring = slot->ring;
+  }
+
+  // the counters must start at zero; the rings need no clearing (a parked sum is read only
+  // after it was written)
   RT_HIP(hipMemsetAsync(slot->counters, 0, sizeof(rt::Counters), stream));
   const int ev = (int)(ctx().launches % kEventRing);
   RT_HIP(hipEventRecord(ctx().ev_begin[ev], stream));
   RT_HIP(rt::launch_trace(p, strict, accel, mfma, blocks, stream));
   RT_HIP(hipEventRecord(ctx().ev_end[ev], stream));
   ctx().launches++;
-
-  if (p.slices > 1) {
-    rp.partial = slot->partial;
-    rp.slices = p.slices;
-    RT_HIP(rt::launch_reduce(rp, stream));
-  }
 
   slot->launch_no = ctx().launches;
   slot->last = {};
@@ -801,8 +791,8 @@ int init_context(int device) {
   na = LaunchSlot();
   na.bound = true;
   na.counters = reinterpret_cast<rt::Counters*>(base);
-  na.partial = reinterpret_cast<float*>(static_cast<unsigned char*>(base) + kScratchCounterBytes);
-  na.partial_cap = kScratchPlaneBytes / sizeof(float);
+  na.ring = reinterpret_cast<float*>(static_cast<unsigned char*>(base) + kScratchCounterBytes);
+  na.ring_cap = kScratchPlaneBytes / sizeof(float);
   for (int i = 0; i < kEventRing; ++i) {
     RT_HIP(hipEventCreate(&ctx().ev_begin[i]));
     RT_HIP(hipEventCreate(&ctx().ev_end[i]));
@@ -824,7 +814,7 @@ void destroy_context() {
   }
   for (LaunchSlot& sl : ctx().slots) {
     if (sl.counters) (void)hipFree(sl.counters);
-    if (sl.partial) (void)hipFree(sl.partial);
+    if (sl.ring) (void)hipFree(sl.ring);
   }
   FrameCache& fc = ctx().cache;
   if (fc.done) (void)hipEventDestroy(fc.done);
@@ -1144,6 +1134,11 @@ int rt_get_phase_cycles(uint64_t* out16) {
     RT_HIP(hipMemcpy(&c, sl.counters, sizeof c, hipMemcpyDeviceToHost));
   }
   for (int i = 0; i < 16; ++i) out16[i] = c.phase[i];
+#ifdef RT_DIAG_RING
+  // developer build: slots 8-11 carry the waves' open-pixel statistics instead of drain steps
+  // (steps starved of slots, path slots idle in them, merges, pixels merged)
+  for (int i = 0; i < 4; ++i) out16[8 + i] = c.phase[16 + i];
+#endif
 #ifdef RT_DIAG_TRIGGERS
   // developer build: slots 8-10 carry the scan's branch statistics instead of drain steps
   for (int i = 0; i < 3; ++i) out16[8 + i] = c.phase[16 + i];

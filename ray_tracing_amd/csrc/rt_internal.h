@@ -45,12 +45,24 @@ constexpr int trace_threads(bool multi, bool accel, bool mfma = false) {
 constexpr int kRaysPerLane = RT_RAYS_PER_LANE;   // independent paths blocked into one lane
 constexpr uint32_t kListEntries = 512;  // candidates a wave can list between two replays
 constexpr int kScanUnroll = 4;          // spheres per unrolled block of the scan
-constexpr uint32_t kChunkSpheres = 1200; // spheres resident in LDS at a time: with the read-ahead
+constexpr uint32_t kChunkSpheres = 1136; // spheres resident in LDS at a time: with the read-ahead
                                          // padding and the waves' candidate lists, two workgroups
                                          // of kThreads fill a CU's LDS
 constexpr size_t kLdsPerWorkgroup = 160 * 1024 / 2;   // two workgroups share a CU's 160 KB
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic
+constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic: that many whole
+                                        // pixels when a pixel is one item, otherwise the largest
+                                        // whole number of pixels (1 to kGrabPixelsMax) whose
+                                        // slices fit (grab_pixels in TraceParams)
+constexpr uint32_t kGrabPixelsMax = 4;
+// Sliced samples: every slice of a pixel is run by lanes of ONE wave (a wave reserves whole
+// pixels), each slice's sum is parked in the wave's own ring in device memory, and once a pixel's
+// last slice is in, the wave adds the parked sums in slice order and writes the pixel.  A wave
+// holds at most kRingSlots pixels open; per wave in LDS: where each open pixel goes in the output
+// and how many of its slices are in (one byte each).
+constexpr uint32_t kRingSlots = 32;
+constexpr size_t kSlotTableBytes = kRingSlots * sizeof(uint32_t) + kRingSlots;
+constexpr uint32_t kMergeBatch = 8;     // pixels that wait for each other before a wave merges them
 constexpr uint32_t kTargetItems = 1u << 20; // below this many pixels, split samples over lanes
 constexpr uint32_t kSamplesPerItem = 8;     // samples one full-size work item runs
 #ifndef RT_MAX_SLICES
@@ -181,10 +193,12 @@ struct TraceParams {
   uint32_t width, height;
   uint32_t max_depth, spp;
   uint32_t seed_a, seed_b;  // rt_rng_seed_a/b(seed)
-  uint32_t slices;          // work items (and partial-sum planes) per pixel
-  uint32_t body_slices;     // the first body_slices slices are issued first, pixel-major;
-                            // the remaining (short) ones after them, pixel-major again
-  Divider body_div, tail_div;   // division by body_slices and by slices - body_slices
+  uint32_t slices;          // work items per pixel; item = pixel * slices + slice
+  Divider slices_div;       // division by slices
+  uint32_t grab_pixels;     // pixels a wave reserves at a time
+  uint32_t ring_slots;      // slices > 1: pixels a wave can hold open (<= kRingSlots)
+  uint32_t slot_table_offset;   // RT_FLAG_ACCEL: where the waves' slot tables start in LDS
+  float* ring;              // slices > 1: [wave][ring_slots][slices][3] parked slice sums
   uint32_t slice_begin[kMaxSlices + 1];   // slice k runs samples [slice_begin[k], slice_begin[k+1])
   uint32_t n_tiles;
   uint32_t total_pixels;
@@ -199,28 +213,23 @@ struct TraceParams {
   uint32_t row_block, row_period;
   uint64_t out_period;
   Divider row_block_div;
-  float* out;               // final buffer (slices == 1) or partial-sum buffer
-  int resolve;              // apply x*(1/spp), sqrt, clamp on the way out (slices == 1 only)
+  float* out;               // the call's output
+  int resolve;              // apply x*(1/spp), sqrt, clamp on the way out
   uint32_t bvh_stack;       // RT_FLAG_ACCEL: rows of the traversal stack (levels of the tree)
   int bvh_in_lds;           // RT_FLAG_ACCEL: the workgroup keeps a copy of the hierarchy in LDS
-  int accumulate;           // slices == 1 only: an item's running sum starts from what `out`
-                            // already holds instead of zero (progressive rendering)
+  int accumulate;           // progressive rendering: a pixel's sum is added to what `out` holds
+                            // (one item per pixel: its running sum starts from that value)
   float inv_spp;
   Counters* counters;
 };
 
-struct ReduceParams {
-  const float* partial;   // [out_pixels][slices][3]
-  float* out;             // [out_pixels][3]
-  uint64_t out_pixels;
-  uint32_t slices;
+// zero_kernel: the pixels a call's tiles cover, set to (0, 0, 0) (a frame at max_depth 0).
+struct ZeroParams {
+  float* out;             // [out pixels][3]
   uint32_t n_tiles;
-  uint32_t total_pixels;  // pixels the tiles cover; only these are summed and written
+  uint32_t total_pixels;  // pixels the tiles cover; only these are written
   TileDev tile0;
   const TileDev* tiles;
-  int resolve;
-  int accumulate;         // out = out + (sum of the planes) instead of out = sum of the planes
-  float inv_spp;
 };
 
 // compose_final_framebuffer's arithmetic over a buffer of sums (progressive rendering).
@@ -243,14 +252,14 @@ struct HookParams {
 
 // Launchers implemented in rt_kernels.hip.  `strict` selects the non-contracted discriminant.
 size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint32_t bvh_depth,
-                       bool* bvh_in_lds);
+                       bool* bvh_in_lds, uint32_t* slot_table_offset = nullptr);
 uint32_t bvh_stack_depth();
 size_t trace_lds_bytes_mfma(int threads);
 hipError_t trace_max_blocks_per_cu(bool strict, bool multi, bool accel, size_t lds_bytes, int* out);
 hipError_t trace_max_blocks_per_cu_mfma(bool multi, size_t lds_bytes, int* out);
 hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, bool mfma, int blocks,
                         hipStream_t stream);
-hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream);
+hipError_t launch_zero(const ZeroParams& p, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream);
 hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream);
 

@@ -95,6 +95,9 @@ struct PhaseClock {
   unsigned long long trig_cycles, prep_cycles;   // diagnostic: inside the candidate code, building columns
   unsigned long long blocks, trig_blocks, trig_pairs;   // scan blocks, those that branched to the
                                                         // queueing code, (sphere, path) pairs queued there
+  unsigned long long starved_steps, starved_idle;   // steps a wave could not reserve pixels for
+                                                    // want of slots; path slots left idle in them
+  unsigned long long merges, merged_pixels;         // calls of merge_ready, pixels they wrote
 };
 
 #ifndef RT_MIN_WAVES
@@ -117,9 +120,11 @@ static_assert(L >= (uint32_t)(U * R * kWave), "an empty list must take whatever 
 constexpr uint32_t kListMark = L - (uint32_t)kWave;
 constexpr size_t kWaveListBytes = (size_t)L * sizeof(uint32_t) + (size_t)kSlots * sizeof(unsigned long long) +
                                   (size_t)kSlots * 2 * sizeof(float4);
-// ... and, last, the list's length while the matrix scan appends to it (16 bytes keep the next
-// wave's list aligned)
-constexpr size_t kWaveLdsBytes = kWaveListBytes + 16;
+// ... then four words: the list's length while the matrix scan appends to it, "keys live", the
+// mask of open pixels whose slices are all in (SlotTable::ready), one spare; and, last, the
+// wave's table of open pixels (SlotTable)
+constexpr size_t kWaveLdsBytes = kWaveListBytes + 16 + kSlotTableBytes;
+static_assert(kWaveLdsBytes % 16 == 0, "the next wave's list must stay 16-byte aligned");
 constexpr unsigned long long kNoHit = ~0ull;
 constexpr float kTMin = 0.001f;  // src/main.rs:196
 constexpr float kTMax = FLT_MAX; // f32::MAX, src/main.rs:196
@@ -1343,31 +1348,89 @@ __device__ __forceinline__ void bvh_hit(Path& P, const SceneDev& sc, const BvhSo
   P.best = best;
 }
 
+// ---- sliced samples: a wave's open pixels ------------------------------------------------------
+// With more than one slice per pixel a wave reserves WHOLE pixels, so every slice of a pixel is
+// run by one of its lanes.  A lane adds its slice's samples in registers, in sample order, parks
+// the sum in the wave's ring (device memory, [slot][slice][3]) and counts it in; when a pixel's
+// last slice is in, the pixel is marked ready, and the wave adds ready pixels' parked sums in
+// slice order - one lane per (pixel, channel) - and writes them out (merge_ready).  The sum of a
+// pixel is therefore a function of the frame alone: it does not depend on which lane ran which
+// slice, on the order in which they finished, on tiling or on the number of GPUs.
+struct SlotTable {
+  uint32_t* out_at;   // [kRingSlots] where the open pixel goes in the call's output
+  uint32_t* cnt;      // [kRingSlots / 4] slices that are in, one byte per slot
+};
+// The slots whose pixel has every slice in, as a wave-uniform mask: lane s looks at slot s's
+// byte.  Called by all 64 lanes.
+__device__ __forceinline__ uint32_t ready_slots(const SlotTable& st, uint32_t slices, uint32_t lane) {
+  const unsigned char* bytes = reinterpret_cast<const unsigned char*>(st.cnt);
+  const uint32_t mine = lane < kRingSlots ? bytes[lane] : 0u;
+  return (uint32_t)__builtin_amdgcn_ballot_w64(mine == slices);
+}
+struct RingState {                 // wave-uniform
+  uint32_t free_mask;              // slots that hold no pixel
+  uint32_t map;                    // the current reservation's slots: byte j = the slot of its
+                                   // j-th pixel counted from the LAST one
+  bool starved;                    // a reservation was wanted and too few slots were free
+};
+// Where a wave's ring starts in p.ring, in floats.  Formed where it is used, from a thread index
+// the compiler cannot see through, so that it is not kept in registers across the main loop.
+__device__ __forceinline__ size_t ring_offset(const TraceParams& p) {
+  uint32_t t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return (size_t)(blockIdx.x * (blockDim.x / kWave) + t / kWave) * ((size_t)p.ring_slots * 3u * p.slices);
+}
+
 // Reserve work for the lanes of this wave whose `need` is set.  Returns the lane's item or
-// kNone once the frame's items are exhausted.  Must be called by all 64 lanes.
+// kNone (the frame's items are exhausted, or the wave holds too many pixels open to reserve
+// another group: rs.starved); `slot` is the ring slot of the item's pixel.  Must be called by
+// all 64 lanes.
 __device__ __forceinline__ uint32_t wave_fetch(bool need, uint32_t& next, uint32_t& end,
-                                               bool& exhausted, const TraceParams& p,
-                                               uint32_t lane) {
+                                               bool& exhausted, RingState& rs, uint32_t& slot,
+                                               const TraceParams& p, uint32_t lane) {
   uint32_t item = kNone;
+  slot = 0;
+  const bool sliced = p.slices != 1;
   unsigned long long mask = __builtin_amdgcn_ballot_w64(need);
   while (mask != 0 && !exhausted) {
     if (next == end) {
+      if (sliced && (uint32_t)__builtin_popcount(rs.free_mask) < p.grab_pixels) {
+        rs.starved = true;
+        break;
+      }
       uint32_t g = 0;
       if (lane == 0) g = atomicAdd(&p.counters->next_grab, 1u);
       g = __builtin_amdgcn_readfirstlane(g);
-      const unsigned long long first = (unsigned long long)g * kItemsPerGrab;
-      if (first >= p.total_items) {
+      const unsigned long long first = (unsigned long long)g * p.grab_pixels;
+      if (first >= p.total_pixels) {
         exhausted = true;
         break;
       }
-      next = (uint32_t)first;
-      end = p.total_items - next < kItemsPerGrab ? p.total_items : next + kItemsPerGrab;
+      const uint32_t left = p.total_pixels - (uint32_t)first;
+      const uint32_t np = left < p.grab_pixels ? left : p.grab_pixels;
+      next = (uint32_t)first * p.slices;   // below 2^32: checked on the host
+      end = next + np * p.slices;
+      if (sliced) {
+        rs.map = 0;
+        for (uint32_t i = 0; i < np; ++i) {
+          const uint32_t s = (uint32_t)__builtin_ctz(rs.free_mask);
+          rs.free_mask &= rs.free_mask - 1;
+          rs.map = (rs.map << 8) | s;
+        }
+      }
     }
     const uint32_t avail = end - next;
     const bool asking = (mask >> lane) & 1ull;
     const uint32_t rank = __builtin_popcountll(mask & ((1ull << lane) - 1ull));
     const bool mine = asking && rank < avail;
-    if (mine) item = next + rank;
+    if (mine) {
+      item = next + rank;
+      if (sliced) {
+        uint32_t j = 0;   // pixels of the reservation behind this item's
+        if (p.grab_pixels != 1) j = fast_div(end - 1u - item, p.slices_div);
+        slot = (rs.map >> (8 * j)) & 0xFFu;
+      }
+    }
     const uint32_t want = __builtin_popcountll(mask);
     next += want < avail ? want : avail;
     mask = __builtin_amdgcn_ballot_w64(asking && !mine);
@@ -1387,23 +1450,14 @@ __device__ __forceinline__ TileDev find_tile(uint32_t g, uint32_t n_tiles, const
   return tiles[lo];
 }
 
-// Item numbering: first every pixel's body slices, pixel-major (the lanes of a wave then sit
-// on the same few pixels, so their paths meet the same spheres and fewer scan blocks branch
-// to the candidate code); then every pixel's short tail slices, pixel-major again, so that
-// the items that drain last are small.
-__device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TraceParams& p) {
+// Item numbering: pixel-major, item = pixel * slices + slice (the short slices that end a
+// pixel's plan come last within the pixel).
+__device__ __forceinline__ void setup_item(Path& P, uint32_t item, uint32_t slot, const TraceParams& p,
+                                           const SlotTable& st) {
   uint32_t g = item, sl = 0;
   if (p.slices != 1) {
-    const uint32_t body_items = p.total_pixels * p.body_slices;
-    if (item < body_items) {
-      g = fast_div(item, p.body_div);
-      sl = item - g * p.body_slices;
-    } else {
-      const uint32_t tail_slices = p.slices - p.body_slices;
-      const uint32_t j = item - body_items;
-      g = fast_div(j, p.tail_div);
-      sl = p.body_slices + (j - g * tail_slices);
-    }
+    g = fast_div(item, p.slices_div);
+    sl = item - g * p.slices;
   }
   const TileDev t = find_tile(g, p.n_tiles, p.tile0, p.tiles);
   const uint32_t local = g - t.first_pixel;
@@ -1420,15 +1474,19 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, const TracePa
   P.fx = (float)px;
   P.fy = (float)py;
   P.pixel = py * p.width + px;
-  // Where the item's sum goes: the pixel's place in the output, or, with sliced samples, entry
-  // `sl` of the pixel's run of `slices` partial sums.  The items a wave reserves together are
-  // the slices of one or two pixels, so their stores fill whole cache lines of one L2.  All
-  // below 2^32 (checked on the host), so 32-bit arithmetic does.
-  P.out_index = p.slices != 1 ? at * p.slices + sl : at;
+  // Where the item's sum goes: the pixel's place in the output (below 2^32: checked on the
+  // host), or, with sliced samples, entry `sl` of the pixel's slot in the wave's ring; the lane
+  // that runs a pixel's first slice notes where the pixel goes.
+  if (p.slices != 1) {
+    P.out_index = (slot << 8) | sl;
+    if (sl == 0) st.out_at[slot] = at;
+  } else {
+    P.out_index = at;
+  }
   P.sample = p.slice_begin[sl];
   P.sample_end = p.slice_begin[sl + 1];
   P.ar = P.ag = P.ab = 0.0f;
-  if (p.accumulate) {
+  if (p.accumulate && p.slices == 1) {
     // progressive rendering with the whole pass in one item: carry on from the sum so far,
     // `pixel_color += color` (src/cpu/job.rs:58) continuing where the last pass stopped
     const float* o = p.out + 3ull * P.out_index;
@@ -1467,8 +1525,18 @@ __device__ __forceinline__ void start_sample(Path& P, const TraceParams& p) {
   P.alive = true;
 }
 
-__device__ __forceinline__ void write_item(const Path& P, const TraceParams& p) {
+__device__ __forceinline__ void write_item(const Path& P, const TraceParams& p, const SlotTable& st) {
   float r = P.ar, g = P.ag, b = P.ab;
+  if (p.slices != 1) {
+    // park the slice's sum and count it in
+    const uint32_t slot = P.out_index >> 8, sl = P.out_index & 0xFFu;
+    float* o = p.ring + ring_offset(p) + slot * (3u * p.slices) + 3u * sl;
+    o[0] = r; o[1] = g; o[2] = b;
+    // (nothing waits for the count: the wave looks at its slots' counts now and then, ready_slots)
+    (void)__hip_atomic_fetch_add(st.cnt + (slot >> 2), 1u << ((slot & 3u) * 8u), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return;
+  }
   if (p.resolve) {
     r = resolve_channel(r, p.inv_spp);
     g = resolve_channel(g, p.inv_spp);
@@ -1476,6 +1544,53 @@ __device__ __forceinline__ void write_item(const Path& P, const TraceParams& p) 
   }
   float* o = p.out + 3ull * P.out_index;
   o[0] = r; o[1] = g; o[2] = b;
+}
+
+// The wave's ready pixels: sum of the parked slice sums in slice order (`pixel_color += color`,
+// src/cpu/job.rs:58, over slices instead of samples), then compose_final_framebuffer's arithmetic
+// when asked for (src/cpu/mod.rs:67-75).  One lane per (pixel, channel), up to 21 pixels at a
+// time; the slots go back to the free set.  Called by all 64 lanes; `ready` is wave-uniform and
+// not zero.
+__device__ __forceinline__ void merge_ready(uint32_t ready, const TraceParams& p, const SlotTable& st,
+                                            RingState& rs, uint32_t lane) {
+  // the parked sums were stored by lanes of this wave: wait until the stores have left it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t group = lane / 3u, c = lane - 3u * group;
+  const float* ring_wave = p.ring + ring_offset(p);
+  rs.free_mask |= ready;
+  while (ready != 0) {
+    uint32_t slot = kNone;
+    for (uint32_t k = 0; k < 21u && ready != 0; ++k) {
+      const uint32_t s = (uint32_t)__builtin_ctz(ready);
+      ready &= ready - 1;
+      if (group == k) slot = s;
+    }
+    if (slot != kNone) {
+      // read through to the L2 (the lines of a slot were read before, for the pixel it held
+      // last, and written since)
+      const float* src = ring_wave + slot * (3u * p.slices) + c;
+      const auto parked = [&](uint32_t sl) {
+        return __hip_atomic_load(src + 3u * sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      float v = parked(0);
+      uint32_t sl = 1;
+      for (; sl + 8 <= p.slices; sl += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = parked(sl + (uint32_t)u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+      }
+      for (; sl < p.slices; ++sl) v += parked(sl);
+      float* dst = p.out + 3ull * st.out_at[slot] + c;
+      if (p.accumulate) v = *dst + v;
+      if (p.resolve) v = resolve_channel(v, p.inv_spp);
+      *dst = v;
+      if (c == 0)
+        __hip_atomic_fetch_and(st.cnt + (slot >> 2), ~(0xFFu << ((slot & 3u) * 8u)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  }
 }
 
 [[maybe_unused]] __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
@@ -1529,6 +1644,23 @@ void trace_kernel(const TraceParams p) {
   wl.count = 0;
   if (!ACCEL) wl.counter[1] = 0u;   // (the traversal keeps no lists: its LDS holds stacks and the hierarchy)
   wl.redo_from = kNone;
+  // the wave's open pixels (sliced samples): behind its lists, or, for the traversal, where the
+  // host put the tables
+  SlotTable st;
+  {
+    unsigned char* tab = ACCEL ? reinterpret_cast<unsigned char*>(lds) + p.slot_table_offset +
+                                     wave * (kSlotTableBytes + 16)
+                               : wave_lds + kWaveListBytes;
+    st.out_at = reinterpret_cast<uint32_t*>(tab + 16);
+    st.cnt = st.out_at + kRingSlots;
+    if (lane < kRingSlots / 4) st.cnt[lane] = 0u;
+  }
+  const uint32_t all_slots = p.ring_slots >= 32u ? ~0u : (1u << p.ring_slots) - 1u;
+  RingState rs;
+  rs.free_mask = all_slots;
+  rs.map = 0;
+  rs.starved = false;
+  const bool sliced = p.slices != 1;
 
   if (!MULTI && !ACCEL) {
     if (MFMA) stage_chunk_mfma(p.scene, 0, n, mrows, mgeom, mindex, mkhalf);
@@ -1584,22 +1716,42 @@ void trace_kernel(const TraceParams p) {
   for (;;) {
     RT_MARK("refill");
     // ---- refill: next sample of the item, or the next item ------------------------------
+    for (;;) {
+      // Ready pixels are merged a few at a time (the wave looks every fourth step), or at once
+      // when the wave needs their slots or has no more work to wait for.
+      if (sliced && (rs.starved || exhausted || (clk.steps & 3u) == 0)) {
+        const uint32_t ready = ready_slots(st, p.slices, lane);
+        if (ready != 0 && (rs.starved || exhausted || (uint32_t)__builtin_popcount(ready) >= kMergeBatch)) {
+#ifdef RT_DIAG_PHASES
+          clk.merges++;
+          clk.merged_pixels += (uint32_t)__builtin_popcount(ready);
+#endif
+          merge_ready(ready, p, st, rs, lane);
+        }
+      }
+      rs.starved = false;
 #pragma unroll
-    for (int r = 0; r < RP; ++r) {
-      const bool need = !P[r].alive && P[r].sample >= P[r].sample_end;
-      if (need && P[r].has_item) {
-        write_item(P[r], p);
-        P[r].has_item = false;
+      for (int r = 0; r < RP; ++r) {
+        const bool need = !P[r].alive && P[r].sample >= P[r].sample_end;
+        if (need && P[r].has_item) {
+          write_item(P[r], p, st);
+          P[r].has_item = false;
+        }
+        uint32_t slot;
+        const uint32_t item = wave_fetch(need, grab_next, grab_end, exhausted, rs, slot, p, lane);
+        if (need && item != kNone) setup_item(P[r], item, slot, p, st);
+        const bool begin = !P[r].alive && P[r].has_item && P[r].sample < P[r].sample_end;
+        // (counted for the wave on the scalar unit: no register per lane, no vector instruction)
+        n_samples += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(begin));
+        if (begin) {
+          start_sample<MFMA>(P[r], p);
+          if (MFMA) mfma_guard(P[r], p.scene.mfma_scale);
+        }
       }
-      const uint32_t item = wave_fetch(need, grab_next, grab_end, exhausted, p, lane);
-      if (need && item != kNone) setup_item(P[r], item, p);
-      const bool begin = !P[r].alive && P[r].has_item && P[r].sample < P[r].sample_end;
-      // (counted for the wave on the scalar unit: no register per lane, no vector instruction)
-      n_samples += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(begin));
-      if (begin) {
-        start_sample<MFMA>(P[r], p);
-        if (MFMA) mfma_guard(P[r], p.scene.mfma_scale);
-      }
+      // Too many pixels open to reserve more: if some of them have become ready in the
+      // meantime, merge them and ask again; otherwise the lanes without work wait a step.
+      if (!(sliced && rs.starved)) break;
+      if (ready_slots(st, p.slices, lane) == 0) break;
     }
     if constexpr (!ACCEL) {
       // Out of work: a lane whose first path slot is finished takes its second slot's path into
@@ -1618,16 +1770,29 @@ void trace_kernel(const TraceParams p) {
     bool any_alive = false;
 #pragma unroll
     for (int r = 0; r < RP; ++r) any_alive = any_alive || P[r].alive;
-    const bool wave_alive = __builtin_amdgcn_ballot_w64(any_alive) != 0;
+    // (a wave whose paths have all ended may still hold pixels open, all of them ready: it goes
+    // round once more, merges them - it is starved or out of work, or it would have found work
+    // above - and then either finds work or ends)
+    const bool pending = sliced && rs.free_mask != all_slots;
+    const bool wave_alive = __builtin_amdgcn_ballot_w64(any_alive) != 0 || pending;
     if (MULTI) {
       if (!__syncthreads_or(wave_alive ? 1 : 0)) break;   // workgroup-uniform
     } else {
       if (!wave_alive) break;
+      if (__builtin_amdgcn_ballot_w64(any_alive) == 0) continue;   // only ready pixels: no step
     }
 
     RT_STAMP(clk.refill, clk.t0);
     RT_MARK("hit_setup");
     clk.steps++;
+#ifdef RT_DIAG_PHASES
+    if (sliced && rs.starved) {
+      clk.starved_steps++;
+#pragma unroll
+      for (int r = 0; r < RP; ++r)
+        clk.starved_idle += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(!P[r].alive));
+    }
+#endif
 
     // ---- World::hit --------------------------------------------------------------------
 #pragma unroll
@@ -1799,6 +1964,14 @@ void trace_kernel(const TraceParams p) {
 #endif
     atomicAdd(&p.counters->phase[13], 1ull);                     // waves
   }
+#ifdef RT_DIAG_RING
+  if (lane == 0) {
+    atomicAdd(&p.counters->phase[16], clk.starved_steps);
+    atomicAdd(&p.counters->phase[17], clk.starved_idle);
+    atomicAdd(&p.counters->phase[18], clk.merges);
+    atomicAdd(&p.counters->phase[19], clk.merged_pixels);
+  }
+#endif
 #ifdef RT_DIAG_TRIGGERS
   // a build for reading the scan's branch rate: {scan blocks, blocks that branched to the
   // queueing code, (sphere, path) pairs queued there}, summed over waves
@@ -1827,61 +2000,16 @@ void trace_kernel(const TraceParams p) {
   }
 }
 
-// Sum the partial sums of each covered pixel in slice order and optionally resolve
-// (compose_final_framebuffer's arithmetic, src/cpu/mod.rs:67-75).  HBM-bound.  A pixel's partial
-// sums are one contiguous run of slices * 3 floats; a workgroup takes kReducePixels pixels at a
-// time, its four waves copy their pixels' runs into LDS with coalesced loads, and one thread per
-// (pixel, channel) then adds that channel's values in slice order.
-constexpr uint32_t kReducePixels = 64;
-__global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
-  extern __shared__ __align__(16) float red[];             // [kReducePixels][slices * 3]
-  __shared__ unsigned long long where[kReducePixels];      // output pixel index of each slot
-  const uint32_t run = p.slices * 3;
-  const uint32_t wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-  for (uint32_t first = blockIdx.x * kReducePixels; first < p.total_pixels;
-       first += gridDim.x * kReducePixels) {
-    if (threadIdx.x < kReducePixels && first + threadIdx.x < p.total_pixels) {
-      const uint32_t g = first + threadIdx.x;
-      const TileDev t = find_tile(g, p.n_tiles, p.tile0, p.tiles);
-      const uint32_t local = g - t.first_pixel;
-      const uint32_t ty = fast_div(local, t.wdiv);
-      const uint32_t tx = local - ty * t.w;
-      where[threadIdx.x] = t.out_offset + (unsigned long long)ty * t.out_stride + tx;
-    }
-    __syncthreads();
-    const uint32_t count = p.total_pixels - first < kReducePixels ? p.total_pixels - first : kReducePixels;
-    // Pixels that follow each other in the output (the rule inside a tile row) form one
-    // contiguous block of count * run floats: copied 16 bytes per thread when it is so aligned.
-    // (every pixel of the group is checked: a caller's own tile offsets need not be monotone)
-    const float* block = p.partial + where[0] * run;
-    const bool in_place = threadIdx.x >= count || where[threadIdx.x] == where[0] + threadIdx.x;
-    const bool contiguous = __syncthreads_and(in_place ? 1 : 0) != 0 &&
-                            (reinterpret_cast<uintptr_t>(block) & 15u) == 0 && ((count * run) & 3u) == 0;
-    if (contiguous) {
-      const float4* src4 = reinterpret_cast<const float4*>(block);
-      float4* red4 = reinterpret_cast<float4*>(red);
-      for (uint32_t i = threadIdx.x; i < count * run / 4; i += 256) red4[i] = src4[i];
-    } else {
-      for (uint32_t k = wave; k < count; k += 256 / kWave) {
-        const float* src = p.partial + where[k] * run;
-        for (uint32_t i = lane; i < run; i += kWave) red[k * run + i] = src[i];
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < count * 3) {
-      const uint32_t k = threadIdx.x / 3, ch = threadIdx.x - 3 * k;
-      float v = 0.0f;                       // slices == 0: the covered pixels are set to zero
-      if (p.slices != 0) {
-        const float* mine = red + k * run + ch;
-        v = mine[0];
-        for (uint32_t sl = 1; sl < p.slices; ++sl) v += mine[3 * sl];
-      }
-      float* dst = p.out + 3ull * where[k] + ch;
-      if (p.accumulate) v = *dst + v;
-      if (p.resolve) v = resolve_channel(v, p.inv_spp);
-      *dst = v;
-    }
-    __syncthreads();
+// A frame at max_depth 0: shoot_ray(ray, 0) is black (src/main.rs:192-194), so every pixel the
+// call's tiles cover is (0, 0, 0) - resolved or not - and nothing is traced.
+__global__ __launch_bounds__(256) void zero_kernel(const ZeroParams p) {
+  for (uint32_t g = blockIdx.x * 256u + threadIdx.x; g < p.total_pixels; g += gridDim.x * 256u) {
+    const TileDev t = find_tile(g, p.n_tiles, p.tile0, p.tiles);
+    const uint32_t local = g - t.first_pixel;
+    const uint32_t ty = fast_div(local, t.wdiv);
+    const uint32_t tx = local - ty * t.w;
+    float* dst = p.out + 3ull * (t.out_offset + (unsigned long long)ty * t.out_stride + tx);
+    dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f;
   }
 }
 
@@ -2034,17 +2162,21 @@ static_assert((size_t)lds_capacity(kChunkSpheres + 1) * (sizeof(float4) + sizeof
 }  // namespace
 
 size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint32_t bvh_depth,
-                       bool* bvh_in_lds) {
+                       bool* bvh_in_lds, uint32_t* slot_table_offset) {
   if (accel) {
     // one stack row per level of the tree (at least one); the copy of the hierarchy goes in
     // when the workgroups that fill a CU's wave slots still all fit into its LDS
     const size_t stacks = (size_t)(bvh_depth ? bvh_depth : 1) * kThreadsAccel * sizeof(uint32_t);
-    const size_t copy = (size_t)bvh_nodes * sizeof(BvhNode) +
-                        (size_t)n_spheres * (sizeof(float4) + sizeof(uint32_t));
+    size_t copy = (size_t)bvh_nodes * sizeof(BvhNode) +
+                  (size_t)n_spheres * (sizeof(float4) + sizeof(uint32_t));
+    copy = (copy + 15) & ~(size_t)15;
+    // the waves' tables of open pixels come last
+    const size_t tables = (size_t)(kThreadsAccel / kWave) * (kSlotTableBytes + 16);
     constexpr size_t wgs_per_cu = (size_t)RT_ACCEL_WAVES * 4 * kWave / kThreadsAccel;
-    const bool fits = stacks + copy <= 160 * 1024 / wgs_per_cu;
+    const bool fits = stacks + copy + tables <= 160 * 1024 / wgs_per_cu;
     if (bvh_in_lds) *bvh_in_lds = fits;
-    return fits ? stacks + copy : stacks;
+    if (slot_table_offset) *slot_table_offset = (uint32_t)(fits ? stacks + copy : stacks);
+    return (fits ? stacks + copy : stacks) + tables;
   }
   return (size_t)lds_capacity(n_spheres) * (sizeof(float4) + sizeof(float)) +
          queue_bytes(trace_threads(n_spheres > kChunkSpheres, false));
@@ -2119,12 +2251,11 @@ hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, bool mfma
   return hipGetLastError();
 }
 
-hipError_t launch_reduce(const ReduceParams& p, hipStream_t stream) {
-  uint64_t blocks = ((uint64_t)p.total_pixels + kReducePixels - 1) / kReducePixels;
-  if (blocks > 16384) blocks = 16384;
+hipError_t launch_zero(const ZeroParams& p, hipStream_t stream) {
+  uint64_t blocks = ((uint64_t)p.total_pixels + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
   if (blocks == 0) return hipSuccess;
-  const size_t lds = (size_t)kReducePixels * (p.slices ? p.slices : 1) * 3 * sizeof(float);
-  hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

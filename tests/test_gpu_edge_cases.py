@@ -51,11 +51,11 @@ def test_tile_shapes(tile):
     check(s, m, 33, 21, 2, tile=tile)
 
 
-# 1200 spheres is the vector filter's chunk, 512 rows the matrix filter's (one of the four big
+# 1136 spheres is the vector filter's chunk, 512 rows the matrix filter's (one of the four big
 # spheres kept first, the ground, has no row: 513 spheres are 512 rows and a second chunk that
 # holds nothing but the listed sphere)
-@pytest.mark.parametrize("n", [0, 1, 2, 5, 511, 512, 513, 514, 1024, 1025, 1199, 1200, 1201, 1537,
-                               2016, 2400, 2401, 4033])
+@pytest.mark.parametrize("n", [0, 1, 2, 5, 511, 512, 513, 514, 1024, 1025, 1135, 1136, 1137, 1537,
+                               2016, 2272, 2273, 4033])
 def test_sphere_counts_around_the_lds_chunk(n):
     s, m = O.random_world(1, -33, 33)        # 4360 spheres to cut from
     keep = np.r_[len(s) - 4:len(s), 0:len(s) - 4][:n]   # the four big ones first
