@@ -1716,12 +1716,15 @@ void trace_kernel(const TraceParams p) {
   for (;;) {
     RT_MARK("refill");
     // ---- refill: next sample of the item, or the next item ------------------------------
-    for (;;) {
-      // Ready pixels are merged a few at a time (the wave looks every fourth step), or at once
-      // when the wave needs their slots or has no more work to wait for.
-      if (sliced && (rs.starved || exhausted || (clk.steps & 3u) == 0)) {
+    // Ready pixels are merged a few at a time (the wave looks every fourth step), or at once
+    // when the wave is about to reserve pixels and has too few free slots, or has no more work
+    // to wait for.
+    if (sliced) {
+      const bool short_of_slots = grab_next == grab_end &&
+                                  (uint32_t)__builtin_popcount(rs.free_mask) < p.grab_pixels;
+      if (short_of_slots || exhausted || (clk.steps & 3u) == 0) {
         const uint32_t ready = ready_slots(st, p.slices, lane);
-        if (ready != 0 && (rs.starved || exhausted || (uint32_t)__builtin_popcount(ready) >= kMergeBatch)) {
+        if (ready != 0 && (short_of_slots || exhausted || (uint32_t)__builtin_popcount(ready) >= kMergeBatch)) {
 #ifdef RT_DIAG_PHASES
           clk.merges++;
           clk.merged_pixels += (uint32_t)__builtin_popcount(ready);
@@ -1729,29 +1732,25 @@ void trace_kernel(const TraceParams p) {
           merge_ready(ready, p, st, rs, lane);
         }
       }
-      rs.starved = false;
+    }
+    rs.starved = false;
 #pragma unroll
-      for (int r = 0; r < RP; ++r) {
-        const bool need = !P[r].alive && P[r].sample >= P[r].sample_end;
-        if (need && P[r].has_item) {
-          write_item(P[r], p, st);
-          P[r].has_item = false;
-        }
-        uint32_t slot;
-        const uint32_t item = wave_fetch(need, grab_next, grab_end, exhausted, rs, slot, p, lane);
-        if (need && item != kNone) setup_item(P[r], item, slot, p, st);
-        const bool begin = !P[r].alive && P[r].has_item && P[r].sample < P[r].sample_end;
-        // (counted for the wave on the scalar unit: no register per lane, no vector instruction)
-        n_samples += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(begin));
-        if (begin) {
-          start_sample<MFMA>(P[r], p);
-          if (MFMA) mfma_guard(P[r], p.scene.mfma_scale);
-        }
+    for (int r = 0; r < RP; ++r) {
+      const bool need = !P[r].alive && P[r].sample >= P[r].sample_end;
+      if (need && P[r].has_item) {
+        write_item(P[r], p, st);
+        P[r].has_item = false;
       }
-      // Too many pixels open to reserve more: if some of them have become ready in the
-      // meantime, merge them and ask again; otherwise the lanes without work wait a step.
-      if (!(sliced && rs.starved)) break;
-      if (ready_slots(st, p.slices, lane) == 0) break;
+      uint32_t slot;
+      const uint32_t item = wave_fetch(need, grab_next, grab_end, exhausted, rs, slot, p, lane);
+      if (need && item != kNone) setup_item(P[r], item, slot, p, st);
+      const bool begin = !P[r].alive && P[r].has_item && P[r].sample < P[r].sample_end;
+      // (counted for the wave on the scalar unit: no register per lane, no vector instruction)
+      n_samples += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(begin));
+      if (begin) {
+        start_sample<MFMA>(P[r], p);
+        if (MFMA) mfma_guard(P[r], p.scene.mfma_scale);
+      }
     }
     if constexpr (!ACCEL) {
       // Out of work: a lane whose first path slot is finished takes its second slot's path into
@@ -1771,15 +1770,14 @@ void trace_kernel(const TraceParams p) {
 #pragma unroll
     for (int r = 0; r < RP; ++r) any_alive = any_alive || P[r].alive;
     // (a wave whose paths have all ended may still hold pixels open, all of them ready: it goes
-    // round once more, merges them - it is starved or out of work, or it would have found work
-    // above - and then either finds work or ends)
+    // round once more - an empty step - and merges them above, being short of slots or out of
+    // work, or it would have found work; then it either finds work or ends)
     const bool pending = sliced && rs.free_mask != all_slots;
     const bool wave_alive = __builtin_amdgcn_ballot_w64(any_alive) != 0 || pending;
     if (MULTI) {
       if (!__syncthreads_or(wave_alive ? 1 : 0)) break;   // workgroup-uniform
     } else {
       if (!wave_alive) break;
-      if (__builtin_amdgcn_ballot_w64(any_alive) == 0) continue;   // only ready pixels: no step
     }
 
     RT_STAMP(clk.refill, clk.t0);

@@ -9,7 +9,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ISA = os.path.join(ROOT, "ray_tracing_amd", "csrc", "asm", "rt_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+ISA = os.environ.get("RT_ISA") or os.path.join(ROOT, "ray_tracing_amd", "csrc", "asm", "rt_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
 def main():
