@@ -530,10 +530,10 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   p.slices = plan_slices(*frame, slice_begin);
   for (uint32_t k = 0; k <= p.slices; ++k) p.slice_begin[k] = sample_begin + slice_begin[k];
   p.slices_div = rt::make_divider(p.slices);
-  // a wave reserves whole pixels: 64 items when a pixel is one item, otherwise as many pixels as
-  // make up to 100 items (1 to kGrabPixelsMax)
+  // a wave reserves whole pixels: 64 when a pixel is one item, otherwise as many as make up to
+  // kGrabItems items (1 to kGrabPixelsMax)
   p.grab_pixels = p.slices == 1 ? rt::kItemsPerGrab
-                                : std::min(rt::kGrabPixelsMax, std::max(1u, 100u / p.slices));
+                                : std::min(rt::kGrabPixelsMax, std::max(1u, rt::kGrabItems / p.slices));
   p.n_tiles = (uint32_t)n_tiles;
   uint64_t total_pixels = 0;
   for (size_t i = 0; i < n_tiles; ++i) total_pixels += (uint64_t)tiles[i].w * tiles[i].h;
@@ -667,6 +667,16 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   const uint64_t blocks_needed = (lanes_needed + threads - 1) / threads;
   if ((uint64_t)blocks > blocks_needed) blocks = (int)blocks_needed;
   if (blocks < 1) blocks = 1;
+  // A workgroup reserves chunks of the frame for its waves: kChunkGrabs reservations for each of
+  // them while there is plenty of work, shrinking once fewer than RT_GUIDE_FACTOR such chunks per
+  // workgroup are left (see wg_reserve in rt_kernels.hip).  Measured on the benchmark frame and
+  // on one rank's eighth of it: the whole frame does not care (29.7-30.0 ms for chunks of 16 to
+  // 128 pixels), the eighth wants small chunks early (4.77 ms against 5.1-5.25 for 128-pixel
+  // chunks kept to the end).
+  p.chunk_max = p.grab_pixels * (threads / rt::kWave) * rt::kChunkGrabs;
+  p.chunk_min = p.grab_pixels;
+  p.guide_shift = 0;
+  while ((1ull << p.guide_shift) < (uint64_t)RT_GUIDE_FACTOR * (uint64_t)blocks) ++p.guide_shift;
 
   // Sliced samples: every wave of the launch parks the slice sums of its open pixels in a ring
   // of its own, ring_slots pixels long (all of kRingSlots when the memory is the library's to

@@ -50,11 +50,20 @@ constexpr uint32_t kChunkSpheres = 1136; // spheres resident in LDS at a time: w
                                          // of kThreads fill a CU's LDS
 constexpr size_t kLdsPerWorkgroup = 160 * 1024 / 2;   // two workgroups share a CU's 160 KB
 constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr uint32_t kItemsPerGrab = 64;  // work items a wave reserves per atomic: that many whole
-                                        // pixels when a pixel is one item, otherwise the largest
-                                        // whole number of pixels (1 to kGrabPixelsMax) whose
-                                        // slices fit (grab_pixels in TraceParams)
-constexpr uint32_t kGrabPixelsMax = 4;
+constexpr uint32_t kItemsPerGrab = 64;  // pixels a wave reserves at a time when a pixel is one item
+#ifndef RT_GRAB_ITEMS
+#define RT_GRAB_ITEMS 64
+#endif
+constexpr uint32_t kGrabItems = RT_GRAB_ITEMS;   // sliced samples: a wave reserves as many whole
+constexpr uint32_t kGrabPixelsMax = 4;  // pixels (1 to kGrabPixelsMax) as make up to kGrabItems items
+#ifndef RT_CHUNK_GRABS
+#define RT_CHUNK_GRABS 8
+#endif
+#ifndef RT_GUIDE_FACTOR
+#define RT_GUIDE_FACTOR 16
+#endif
+constexpr uint32_t kChunkGrabs = RT_CHUNK_GRABS; // a workgroup's chunk of the frame: this many
+                                                 // reservations for each of its waves, at most
 // Sliced samples: every slice of a pixel is run by lanes of ONE wave (a wave reserves whole
 // pixels), each slice's sum is parked in the wave's own ring in device memory, and once a pixel's
 // last slice is in, the wave adds the parked sums in slice order and writes the pixel.  A wave
@@ -177,7 +186,7 @@ struct SceneDev {
 };
 
 struct Counters {
-  uint32_t next_grab;   // work-distribution cursor, in units of kItemsPerGrab items
+  uint32_t next_pixel;  // work-distribution cursor: the first pixel no wave has reserved yet
   uint32_t pad;
   unsigned long long rays;     // World::hit calls
   unsigned long long samples;  // shoot_ray calls from the pixel loop
@@ -195,7 +204,10 @@ struct TraceParams {
   uint32_t seed_a, seed_b;  // rt_rng_seed_a/b(seed)
   uint32_t slices;          // work items per pixel; item = pixel * slices + slice
   Divider slices_div;       // division by slices
-  uint32_t grab_pixels;     // pixels a wave reserves at a time
+  uint32_t grab_pixels;     // pixels a wave reserves at a time from its workgroup's chunk
+  uint32_t chunk_max;       // pixels a workgroup reserves at a time from the frame, at most ...
+  uint32_t chunk_min;       // ... and at least; in between, what is left >> guide_shift
+  uint32_t guide_shift;
   uint32_t ring_slots;      // slices > 1: pixels a wave can hold open (<= kRingSlots)
   uint32_t slot_table_offset;   // RT_FLAG_ACCEL: where the waves' slot tables start in LDS
   float* ring;              // slices > 1: [wave][ring_slots][slices][3] parked slice sums

@@ -120,8 +120,8 @@ static_assert(L >= (uint32_t)(U * R * kWave), "an empty list must take whatever 
 constexpr uint32_t kListMark = L - (uint32_t)kWave;
 constexpr size_t kWaveListBytes = (size_t)L * sizeof(uint32_t) + (size_t)kSlots * sizeof(unsigned long long) +
                                   (size_t)kSlots * 2 * sizeof(float4);
-// ... then four words: the list's length while the matrix scan appends to it, "keys live", the
-// mask of open pixels whose slices are all in (SlotTable::ready), one spare; and, last, the
+// ... then four words: the list's length while the matrix scan appends to it, "keys live", and
+// two that the first two waves lend to the workgroup's work cursor (WgCursor); and, last, the
 // wave's table of open pixels (SlotTable)
 constexpr size_t kWaveLdsBytes = kWaveListBytes + 16 + kSlotTableBytes;
 static_assert(kWaveLdsBytes % 16 == 0, "the next wave's list must stay 16-byte aligned");
@@ -1372,6 +1372,8 @@ struct RingState {                 // wave-uniform
   uint32_t map;                    // the current reservation's slots: byte j = the slot of its
                                    // j-th pixel counted from the LAST one
   bool starved;                    // a reservation was wanted and too few slots were free
+  bool waiting;                    // a reservation was wanted while the workgroup's next chunk
+                                   // was being fetched
 };
 // Where a wave's ring starts in p.ring, in floats.  Formed where it is used, from a thread index
 // the compiler cannot see through, so that it is not kept in registers across the main loop.
@@ -1381,13 +1383,90 @@ __device__ __forceinline__ size_t ring_offset(const TraceParams& p) {
   return (size_t)(blockIdx.x * (blockDim.x / kWave) + t / kWave) * ((size_t)p.ring_slots * 3u * p.slices);
 }
 
+// ---- the frame's work cursor, in two levels ---------------------------------------------------
+// A round trip to the frame's cursor in device memory takes microseconds when every wave of the
+// GPU goes there, and a wave's idle lanes wait for it.  So a WORKGROUP reserves a chunk of pixels
+// there, keeps it as a range in LDS, and its waves reserve their few pixels at a time from that
+// range with an LDS compare-and-swap.  Chunks shrink towards the end of the frame (a chunk's size
+// follows from what was left when the one before it was made), so that the workgroups run out
+// of work together.
+struct WgCursor {
+  unsigned long long* range;   // end << 32 | next, in pixels; all ones: the frame is exhausted
+  uint32_t* lock;              // 1 while a wave is fetching the next chunk
+  uint32_t* chunk;             // pixels the next chunk asks for
+};
+// Reserve up to `want` pixels for this wave.  Returns false when there is none to be had right
+// now: the frame is exhausted (`exhausted` is set), or another wave of the workgroup is fetching
+// the next chunk (ask again next step).  Called by all 64 lanes.
+__device__ __forceinline__ bool wg_reserve(uint32_t want, uint32_t& first, uint32_t& np, bool& exhausted,
+                                           const WgCursor& wg, const TraceParams& p, uint32_t lane) {
+  uint32_t got_first = 0, got = 0;   // got: 0 = nothing now, kNone = exhausted
+  if (lane == 0) {
+    for (;;) {
+      unsigned long long w = __hip_atomic_load(wg.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t nx = (uint32_t)w, en = (uint32_t)(w >> 32);
+      if (nx == kNone) {
+        got = kNone;
+        break;
+      }
+      if (nx < en) {
+        const uint32_t take = en - nx < want ? en - nx : want;
+        if (__hip_atomic_compare_exchange_strong(wg.range, &w, ((unsigned long long)en << 32) | (nx + take),
+                                                 __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          got_first = nx;
+          got = take;
+          break;
+        }
+        continue;   // another wave moved the range: look again
+      }
+      uint32_t unlocked = 0;
+      if (!__hip_atomic_compare_exchange_strong(wg.lock, &unlocked, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_WORKGROUP))
+        break;      // another wave is fetching the next chunk
+      // (the range may have been refilled between the look and the lock)
+      w = __hip_atomic_load(wg.range, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((uint32_t)w == kNone || (uint32_t)w < (uint32_t)(w >> 32)) {
+        __hip_atomic_store(wg.lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        continue;
+      }
+      const uint32_t chunk = __hip_atomic_load(wg.chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t f = atomicAdd(&p.counters->next_pixel, chunk);
+      if (f >= p.total_pixels) {
+        __hip_atomic_store(wg.range, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(wg.lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        got = kNone;
+        break;
+      }
+      const uint32_t left = p.total_pixels - f;
+      const uint32_t c = left < chunk ? left : chunk;
+      const uint32_t guided = (left - c) >> p.guide_shift;
+      __hip_atomic_store(wg.chunk, guided > p.chunk_max ? p.chunk_max : guided < p.chunk_min ? p.chunk_min : guided,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(wg.range, ((unsigned long long)(f + c) << 32) | f, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(wg.lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  got_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)got_first);
+  got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+  if (got == kNone) {
+    exhausted = true;
+    return false;
+  }
+  if (got == 0) return false;
+  first = got_first;
+  np = got;
+  return true;
+}
+
 // Reserve work for the lanes of this wave whose `need` is set.  Returns the lane's item or
-// kNone (the frame's items are exhausted, or the wave holds too many pixels open to reserve
-// another group: rs.starved); `slot` is the ring slot of the item's pixel.  Must be called by
-// all 64 lanes.
+// kNone: the frame's items are exhausted, the wave holds too many pixels open to reserve more
+// (rs.starved), or the workgroup's next chunk is on its way (rs.waiting).  `slot` is the ring
+// slot of the item's pixel.  Must be called by all 64 lanes.
 __device__ __forceinline__ uint32_t wave_fetch(bool need, uint32_t& next, uint32_t& end,
                                                bool& exhausted, RingState& rs, uint32_t& slot,
-                                               const TraceParams& p, uint32_t lane) {
+                                               const WgCursor& wg, const TraceParams& p, uint32_t lane) {
   uint32_t item = kNone;
   slot = 0;
   const bool sliced = p.slices != 1;
@@ -1398,17 +1477,12 @@ __device__ __forceinline__ uint32_t wave_fetch(bool need, uint32_t& next, uint32
         rs.starved = true;
         break;
       }
-      uint32_t g = 0;
-      if (lane == 0) g = atomicAdd(&p.counters->next_grab, 1u);
-      g = __builtin_amdgcn_readfirstlane(g);
-      const unsigned long long first = (unsigned long long)g * p.grab_pixels;
-      if (first >= p.total_pixels) {
-        exhausted = true;
+      uint32_t first = 0, np = 0;
+      if (!wg_reserve(p.grab_pixels, first, np, exhausted, wg, p, lane)) {
+        rs.waiting = !exhausted;
         break;
       }
-      const uint32_t left = p.total_pixels - (uint32_t)first;
-      const uint32_t np = left < p.grab_pixels ? left : p.grab_pixels;
-      next = (uint32_t)first * p.slices;   // below 2^32: checked on the host
+      next = first * p.slices;   // below 2^32: checked on the host
       end = next + np * p.slices;
       if (sliced) {
         rs.map = 0;
@@ -1660,7 +1734,25 @@ void trace_kernel(const TraceParams p) {
   rs.free_mask = all_slots;
   rs.map = 0;
   rs.starved = false;
+  rs.waiting = false;
   const bool sliced = p.slices != 1;
+  // the workgroup's share of the frame's cursor: the spare words of its first two waves' headers
+  // (a wave's four header words: list length, "keys live", two spare)
+  WgCursor wg;
+  {
+    unsigned char* base = ACCEL ? reinterpret_cast<unsigned char*>(lds) + p.slot_table_offset
+                                : wave_lds - wave * kWaveLdsBytes + kWaveListBytes;
+    constexpr size_t stride = ACCEL ? kSlotTableBytes + 16 : kWaveLdsBytes;
+    wg.range = reinterpret_cast<unsigned long long*>(base + 8);
+    wg.lock = reinterpret_cast<uint32_t*>(base + stride + 8);
+    wg.chunk = wg.lock + 1;
+    if (threadIdx.x == 0) {
+      *wg.range = 0ull;   // empty
+      *wg.lock = 0u;
+      *wg.chunk = p.chunk_max;
+    }
+  }
+  __syncthreads();
 
   if (!MULTI && !ACCEL) {
     if (MFMA) stage_chunk_mfma(p.scene, 0, n, mrows, mgeom, mindex, mkhalf);
@@ -1734,6 +1826,7 @@ void trace_kernel(const TraceParams p) {
       }
     }
     rs.starved = false;
+    rs.waiting = false;
 #pragma unroll
     for (int r = 0; r < RP; ++r) {
       const bool need = !P[r].alive && P[r].sample >= P[r].sample_end;
@@ -1742,7 +1835,7 @@ void trace_kernel(const TraceParams p) {
         P[r].has_item = false;
       }
       uint32_t slot;
-      const uint32_t item = wave_fetch(need, grab_next, grab_end, exhausted, rs, slot, p, lane);
+      const uint32_t item = wave_fetch(need, grab_next, grab_end, exhausted, rs, slot, wg, p, lane);
       if (need && item != kNone) setup_item(P[r], item, slot, p, st);
       const bool begin = !P[r].alive && P[r].has_item && P[r].sample < P[r].sample_end;
       // (counted for the wave on the scalar unit: no register per lane, no vector instruction)
@@ -1772,7 +1865,9 @@ void trace_kernel(const TraceParams p) {
     // (a wave whose paths have all ended may still hold pixels open, all of them ready: it goes
     // round once more - an empty step - and merges them above, being short of slots or out of
     // work, or it would have found work; then it either finds work or ends)
-    const bool pending = sliced && rs.free_mask != all_slots;
+    // A wave that found the workgroup's range empty while another wave was fetching the next
+    // chunk goes round too, and asks again.
+    const bool pending = (sliced && rs.free_mask != all_slots) || rs.waiting;
     const bool wave_alive = __builtin_amdgcn_ballot_w64(any_alive) != 0 || pending;
     if (MULTI) {
       if (!__syncthreads_or(wave_alive ? 1 : 0)) break;   // workgroup-uniform
@@ -2152,6 +2247,8 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
 constexpr size_t queue_bytes(int threads) {
   return (size_t)(threads / kWave) * kWaveLdsBytes;
 }
+static_assert(kThreadsSingle >= 2 * kWave && kThreadsAccel >= 2 * kWave,
+              "the workgroup's cursor sits in the headers of its first two waves");
 // the chunked kernel's workgroup: records of one chunk, the waves' lists, 256 bytes of statics
 static_assert((size_t)lds_capacity(kChunkSpheres + 1) * (sizeof(float4) + sizeof(float)) +
                       queue_bytes(kThreads) + 256 <= kLdsPerWorkgroup,
