@@ -268,17 +268,26 @@ int rt_resolve_device_async(const float* d_sums, uint64_t n_pixels, uint32_t sam
 
 /* rt_render_rows_device_async for callers that cannot allocate: code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.
- * Same arguments, same pixels (bit for bit), but the call never allocates, frees or waits: its
- * work counters and the partial sums of sliced samples live in one fixed device buffer that the
- * library holds on every GPU it runs on from load to exit (RT_NOALLOC_PLANE_BYTES of planes).
- * Limits: the rows of one call times the frame's sample slices must fit that buffer
- *   (row_end - row_begin) * image_width * slices * 12 bytes <= RT_NOALLOC_PLANE_BYTES
- * (RT_FLAG_SEQUENTIAL_SUM has one slice and needs no planes at all, so any size passes); a
- * request beyond it fails with RT_ERR_LIMIT and a message that says by how much.  RT_FLAG_ACCEL
- * is accepted only for a scene whose hierarchy an allocating call has already built.
- * Every call on a GPU shares that GPU's buffer: two calls that overlap on one GPU (different
- * streams, or different host threads' streams) RACE; calls on one stream, or otherwise ordered,
- * are fine.  The counters are cleared by each call. */
+ * Same arguments, same pixels (bit for bit), but the call never allocates, frees, waits or
+ * records an event: everything it puts on the stream is two kernel launches (one that clears its
+ * work counters, one that renders), so a call made while the stream is being captured becomes
+ * two kernel nodes of the graph.  Its work counters and the rings in which the waves park the
+ * sums of sliced samples live in one fixed device buffer that the library holds on every GPU it
+ * runs on from load to exit (RT_NOALLOC_PLANE_BYTES of rings).  Frames of any size are accepted:
+ * a wave's ring holds as many open pixels as fit (27 at 50 slices a pixel, against 32 when the
+ * memory is the library's to size), which does not change a pixel.
+ * Limits and conditions:
+ *  - the launch geometry of a kernel variant is queried the first time the variant is used on a
+ *    device (at rt_init for the default, matrix-filter kernels; at the first frame for
+ *    RT_FLAG_SCAN_VALU / RT_FLAG_STRICT_FP / RT_FLAG_ACCEL and each new scene size): a call that
+ *    would need the query while its stream is capturing fails with RT_ERR_INVALID_ARGUMENT;
+ *    render once outside capture first;
+ *  - RT_FLAG_ACCEL is accepted only for a scene whose hierarchy an allocating call has built;
+ *  - rt_get_stats after such a call reports rays and samples, and kernel_ms as NaN;
+ *  - every call on a GPU shares that GPU's buffer: two calls that overlap on one GPU (different
+ *    streams, or different host threads' streams) RACE; calls on one stream, or otherwise
+ *    ordered - the nodes of one captured stream are - are fine.  The counters are cleared by
+ *    each call. */
 #define RT_NOALLOC_PLANE_BYTES (64u << 20)
 int rt_render_rows_device_noalloc(const rt_scene* scene, const rt_frame* frame,
                                   uint32_t row_begin, uint32_t row_end,

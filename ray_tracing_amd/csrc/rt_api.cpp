@@ -481,7 +481,8 @@ int ensure_bvh(const rt_scene* s) {
 // Launch-geometry queries do not change for the life of the process; asking once per device and
 // kernel variant keeps the call path of a frame down to its launches.  (Per device: the matrix
 // kernel's query also raises that kernel's dynamic-LDS limit, which is a per-device attribute.)
-int blocks_per_cu(bool strict, bool multi, bool accel, bool mfma, size_t lds, int* out) {
+int blocks_per_cu(bool strict, bool multi, bool accel, bool mfma, size_t lds, int* out,
+                  hipStream_t capturing = nullptr) {
   struct Entry { bool valid; size_t lds; int per_cu; };
   static std::vector<Entry> cache;
   const size_t at = (size_t)ctx().device * 16 +
@@ -489,6 +490,17 @@ int blocks_per_cu(bool strict, bool multi, bool accel, bool mfma, size_t lds, in
   if (cache.size() <= at) cache.resize(at + 1, Entry{false, 0, 0});
   Entry& e = cache[at];
   if (!e.valid || e.lds != lds) {
+    // (`capturing`: a stream that may be under HIP graph capture, where a query that also sets a
+    // kernel attribute has no place; the caller is told to make the first call outside)
+    if (capturing) {
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(capturing, &st) != hipSuccess) (void)hipGetLastError();
+      if (st != hipStreamCaptureStatusNone)
+        return fail(RT_ERR_INVALID_ARGUMENT,
+                    "first use of this kernel variant and scene size on this device: its launch "
+                    "geometry has to be queried once outside stream capture (render once through "
+                    "any entry point before capturing)");
+    }
     int per_cu = 0;
     if (mfma) RT_HIP(rt::trace_max_blocks_per_cu_mfma(multi, lds, &per_cu));
     else RT_HIP(rt::trace_max_blocks_per_cu(strict, multi, accel, lds, &per_cu));
@@ -658,7 +670,8 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   p.bvh_in_lds = bvh_in_lds ? 1 : 0;
   const bool multi = scene->dev.n_spheres > (mfma ? rt::kMfmaChunk : rt::kChunkSpheres);
   int per_cu = 0;
-  if (int rc = blocks_per_cu(strict, multi, accel, mfma, lds, &per_cu)) return rc;
+  if (int rc = blocks_per_cu(strict, multi, accel, mfma, lds, &per_cu, no_alloc ? stream : nullptr))
+    return rc;
   if (per_cu < 1) return fail(RT_ERR_DEVICE, "trace kernel does not fit on a CU (LDS %zu B)", lds);
   int blocks = per_cu * ctx().cus;
   const uint32_t paths_per_lane = accel ? 1 : rt::kRaysPerLane;
@@ -707,14 +720,26 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
 
   // the counters must start at zero; the rings need no clearing (a parked sum is read only
   // after it was written)
-  RT_HIP(hipMemsetAsync(slot->counters, 0, sizeof(rt::Counters), stream));
-  const int ev = (int)(ctx().launches % kEventRing);
-  RT_HIP(hipEventRecord(ctx().ev_begin[ev], stream));
-  RT_HIP(rt::launch_trace(p, strict, accel, mfma, blocks, stream));
-  RT_HIP(hipEventRecord(ctx().ev_end[ev], stream));
-  ctx().launches++;
+  // (for the entry point that may run under graph capture the clearing is a kernel: two
+  // hipMemsetAsync nodes on the same address in one captured graph were seen to take effect once
+  // per replay, not twice - the second launch of a replay then found the first one's cursor)
+  if (no_alloc) RT_HIP(rt::launch_clear_counters(slot->counters, stream));
+  else RT_HIP(hipMemsetAsync(slot->counters, 0, sizeof(rt::Counters), stream));
+  if (no_alloc) {
+    // nothing but the memset and the kernel goes onto the caller's stream: under graph capture
+    // both become nodes of the graph, and an event pair would not be one this library can read
+    // afterwards (rt_get_stats reports kernel_ms as NaN for such a launch)
+    RT_HIP(rt::launch_trace(p, strict, accel, mfma, blocks, stream));
+    slot->launch_no = 0;
+  } else {
+    const int ev = (int)(ctx().launches % kEventRing);
+    RT_HIP(hipEventRecord(ctx().ev_begin[ev], stream));
+    RT_HIP(rt::launch_trace(p, strict, accel, mfma, blocks, stream));
+    RT_HIP(hipEventRecord(ctx().ev_end[ev], stream));
+    ctx().launches++;
+    slot->launch_no = ctx().launches;
+  }
 
-  slot->launch_no = ctx().launches;
   slot->last = {};
   slot->last.rays_per_lane = paths_per_lane;
   slot->last.slices = p.slices;
@@ -811,6 +836,14 @@ int init_context(int device) {
   ctx().device = device;
   ctx().launches = 0;
   ctx().ready = true;
+  // The launch geometry of the two matrix-filter kernels does not depend on the scene: asked
+  // for here, so that a first frame - possibly one being captured into a graph - finds it.
+  for (int multi = 0; multi < 2; ++multi) {
+    int per_cu = 0;
+    if (int rc = blocks_per_cu(false, multi != 0, false, true, rt::trace_lds_bytes_mfma(rt::kThreadsMfma),
+                               &per_cu))
+      return rc;
+  }
   return RT_OK;
 }
 

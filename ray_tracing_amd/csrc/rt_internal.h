@@ -272,6 +272,7 @@ hipError_t trace_max_blocks_per_cu_mfma(bool multi, size_t lds_bytes, int* out);
 hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, bool mfma, int blocks,
                         hipStream_t stream);
 hipError_t launch_zero(const ZeroParams& p, hipStream_t stream);
+hipError_t launch_clear_counters(Counters* c, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream);
 hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream);
 

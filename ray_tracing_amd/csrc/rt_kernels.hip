@@ -2373,6 +2373,17 @@ hipError_t launch_trace(const TraceParams& p, bool strict, bool accel, bool mfma
   return hipGetLastError();
 }
 
+// The work cursor and the ray / sample counts of a launch, cleared by a kernel of its own (a
+// node like any other when the stream is being captured into a graph).
+__global__ __launch_bounds__(64) void clear_counters_kernel(Counters* c) {
+  uint32_t* words = reinterpret_cast<uint32_t*>(c);
+  for (uint32_t i = threadIdx.x; i < sizeof(Counters) / sizeof(uint32_t); i += 64) words[i] = 0u;
+}
+hipError_t launch_clear_counters(Counters* c, hipStream_t stream) {
+  hipLaunchKernelGGL(clear_counters_kernel, dim3(1), dim3(64), 0, stream, c);
+  return hipGetLastError();
+}
+
 hipError_t launch_zero(const ZeroParams& p, hipStream_t stream) {
   uint64_t blocks = ((uint64_t)p.total_pixels + 255) / 256;
   if (blocks > 8192) blocks = 8192;

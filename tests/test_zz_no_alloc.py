@@ -73,3 +73,51 @@ def test_the_whole_benchmark_frame_in_one_call():
     assert st.slices == 50
     both(scene, cam, 1920, 1080, 100, 0, rows=(512, 560))    # a band of it, right after
     scene.close()
+
+
+def test_two_calls_captured_into_a_graph_and_replayed_twice():
+    """The use the entry point exists for: under stream capture nothing may allocate, wait or
+    query.  Two calls (the two parts of a frame) are captured into one HIP graph; each replay must
+    give the allocating entry point's pixels, and the counters of the last call are readable
+    afterwards (its kernel time is not: no event pair is recorded on a captured stream)."""
+    import math
+    s, m = O.random_world(1, -11, 11)
+    scene = hip.Scene(s, m)
+    other = hip.Scene(s[:77], m)
+    cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, 16 / 9)
+    w, h, spp, cut = 256, 144, 32, 80
+    frame = hip.make_frame(cam, w, h, spp, 50, 11, 0)
+    ref = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    hip.render_rows_device_async(scene, frame, 0, h, True, ref.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+    hip.render_rows_device_async(scene, frame, cut, h, True, ref[cut:].data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = hip.get_stats()                      # of the second part
+    out = torch.zeros_like(ref)
+    graph = torch.cuda.CUDAGraph()
+    refused = None
+    with torch.cuda.graph(graph, stream=torch.cuda.Stream()):
+        sp = torch.cuda.current_stream().cuda_stream
+        hip.render_rows_device_noalloc(scene, frame, 0, cut, True, out.data_ptr(), sp)
+        hip.render_rows_device_noalloc(scene, frame, cut, h, True, out[cut:].data_ptr(), sp)
+        # a kernel variant and scene size this process has not launched yet (the vector filter on
+        # a World of 77 spheres) would need a query first: refused while capturing, and nothing
+        # is enqueued
+        try:
+            hip.render_rows_device_noalloc(other, hip.make_frame(cam, w, h, spp, 50, 11, abi.RT_FLAG_SCAN_VALU),
+                                           0, cut, True, out.data_ptr(), sp)
+        except hip.RtError as e:
+            refused = e
+    assert float(out.abs().max()) == 0.0        # capturing runs nothing
+    for _ in range(2):
+        out.fill_(-3.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    st = hip.get_stats()
+    assert (st.rays, st.samples, st.slices) == (want.rays, want.samples, want.slices)
+    assert math.isnan(st.kernel_ms)
+    assert refused is not None and refused.code == -1 and "capture" in str(refused)
+    scene.close()
+    other.close()
