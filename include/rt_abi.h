@@ -27,7 +27,11 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+/* 2: rt_render renders exactly the listed tiles (a partial list used to be ignored and the whole
+ *    frame rendered); rt_render_multi, rt_accumulate_*, rt_resolve_device_async,
+ *    rt_render_rows_device_noalloc, rt_scene_scan_info and RT_FLAG_SCAN_VALU were added; calls
+ *    from several host threads are serialised behind one lock.  Nothing was removed. */
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
   RT_OK = 0,

@@ -235,9 +235,16 @@ void mfma_row_threshold(uint16_t* row) {   // what meets the three parts of the 
   row[31] = f16_bits((_Float16)0.03125f);
 }
 
-void mfma_row_never(uint16_t* row) {   // a row no ray passes: k = +60000, the rest zero
+// A row no ray passes.  Everything but k is zero, so a ray's entry is -k/2 minus its threshold,
+// and the threshold can be as low as minus the slack taken off it: (2^-16 + 2^-23) |o|^2 + 1.5 *
+// 2^-22 with scaled |o|^2 below 2^31 (kMfmaOriginLimit2 in rt_kernels.hip), i.e. up to 33 024.
+// k is therefore the largest f16 in both its parts: -65 504 stays negative against that.  (A
+// single part of 60 000 was enough for a slack of 2^-17 |o|^2, and not for 2^-16: rays from
+// beyond 0.96 of the origin limit listed the padding rows of a chunk.)
+void mfma_row_never(uint16_t* row) {
   for (int i = 0; i < 32; ++i) row[i] = 0;
-  row[27] = f16_bits((_Float16)60000.0f);
+  row[27] = f16_bits((_Float16)65504.0f);
+  row[28] = f16_bits((_Float16)65504.0f);
   mfma_row_threshold(row);
 }
 

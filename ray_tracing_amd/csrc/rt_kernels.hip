@@ -581,7 +581,8 @@ __device__ __forceinline__ bool candidate_root(float4 s, V3 o, V3 d, float a, fl
 template <bool PERM = false, bool COLLECT = true>
 __device__ __forceinline__ void replay_lists(Path (&P)[R], const float4* sph, const float* sr2,
                                              uint32_t chunk_base, WaveLists& wl, uint32_t lane,
-                                             PhaseClock& clk, const uint32_t* index = nullptr) {
+                                             PhaseClock& clk, const uint32_t* index = nullptr,
+                                             uint32_t limit = kNone) {
   const uint32_t n = wl.count;
   // wave-uniform: every lane reads the same word
   const bool keys_live = __builtin_amdgcn_readfirstlane((int)wl.counter[1]) != 0;
@@ -604,8 +605,11 @@ __device__ __forceinline__ void replay_lists(Path (&P)[R], const float4* sph, co
 #ifdef RT_DIAG_PHASES
       clk.replay_iters++;
 #endif
-      if (j + lane < n) {
-        const uint32_t e = wl.list[j + lane];
+      // (PERM: an entry can only name a position below `limit` - the rows beyond it pass no ray,
+      // see mfma_row_never in rt_api.cpp - and is turned away here should it ever do otherwise,
+      // before its position is used to read a record and a sphere number that do not exist)
+      const uint32_t e = j + lane < n ? wl.list[j + lane] : 0u;
+      if (j + lane < n && (!PERM || (e >> 7) < limit)) {
         const uint32_t slot = e & (kSlots - 1), li = e >> 7;
         const float4 ro = wl.rays[2 * slot], rd = wl.rays[2 * slot + 1];
         const unsigned long long now = wl.keys[slot];
@@ -891,6 +895,8 @@ struct MfmaChunk {
   const h8* rows;          // [4][kMfmaRows]: quarter q of the sphere at position i at rows[q * kMfmaRows + i]
   const float4* geom;      // [kMfmaChunk] (cx, cy, cz, r*r)
   const uint32_t* index;   // [kMfmaChunk] sphere number in the World
+  uint32_t count;          // spheres the chunk holds: positions beyond have rows that no ray passes
+                           // and no record (the replay turns an entry that names one away)
 };
 
 // The spheres outside the filter's range (positions [n_rows, cn) of the chunk): one entry per
@@ -905,7 +911,7 @@ __device__ __forceinline__ void mfma_list_always(Path (&P)[R], const MfmaChunk& 
       const unsigned long long mm = __builtin_amdgcn_ballot_w64(okl);
       const uint32_t k = (uint32_t)__builtin_popcountll(mm);
       if (k == 0) continue;
-      if (wl.count + k > L) replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
+      if (wl.count + k > L) replay_lists<true>(P, m.geom, nullptr, 0, wl, lane, clk, m.index, m.count);
       const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32),
                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
       if (okl) wl.list[wl.count + at] = lane | ((li * R + r) << 6);
@@ -1020,7 +1026,7 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], u
         wl.count = L;
         RT_STAMP(clk.scan, clk.t0);
         RT_PRIO_REST();
-        replay_lists<true, false>(P, m.geom, nullptr, 0, wl, lane, clk, m.index);
+        replay_lists<true, false>(P, m.geom, nullptr, 0, wl, lane, clk, m.index, m.count);
         RT_STAMP(clk.replay, clk.t0);
         RT_PRIO_MFMA();
         __hip_atomic_store(wl.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1733,6 +1739,7 @@ void trace_kernel(const TraceParams p) {
   mc.rows = reinterpret_cast<const h8*>(mrows);
   mc.geom = mgeom;
   mc.index = mindex;
+  mc.count = 0;
   // this wave's candidate lists and hit keys, behind the sphere records
   unsigned char* wave_lds = (MFMA ? reinterpret_cast<unsigned char*>(mkhalf + kMfmaChunk)
                                   : reinterpret_cast<unsigned char*>(sr2 + cap)) + wave * kWaveLdsBytes;
@@ -1784,6 +1791,7 @@ void trace_kernel(const TraceParams p) {
   if (!MULTI && !ACCEL) {
     if (MFMA) stage_chunk_mfma(p.scene, 0, n, mrows, mgeom, mindex, mkhalf);
     else stage_chunk(p.scene, 0, n, sph, sr2);
+    mc.count = n;
     __syncthreads();
   }
   // ACCEL: the LDS holds the traversal stacks instead, one column per thread, and behind them
@@ -1954,6 +1962,7 @@ void trace_kernel(const TraceParams p) {
           const uint32_t cn = n - base < kMfmaChunk ? n - base : kMfmaChunk;
           __syncthreads();   // every wave is done with the previous chunk
           stage_chunk_mfma(p.scene, chunk, cn, mrows, mgeom, mindex);
+          mc.count = cn;
           __syncthreads();
           const uint32_t n_rows = base >= n_in ? 0u : (n_in - base < cn ? n_in - base : cn);
           if (!tail) {
@@ -1962,7 +1971,7 @@ void trace_kernel(const TraceParams p) {
             for (int r = 0; r < R; ++r)
               if (mfma_half_scanned(P[r])) scan_pass_mfma(P, cols[r], (uint32_t)r, mc, n_rows, wl, lane, clk);
             RT_MARK("replay");
-            replay_lists<true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index);
+            replay_lists<true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index, mc.count);
             RT_MARK("replay_end");
             RT_STAMP(clk.replay, clk.t0);
           }
@@ -1985,7 +1994,7 @@ void trace_kernel(const TraceParams p) {
           scan_pass_mfma(P, cols, (uint32_t)r, mc, n_in, wl, lane, clk);
         }
         RT_MARK("replay");
-        replay_lists<true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index);
+        replay_lists<true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index, mc.count);
         RT_MARK("replay_end");
         RT_STAMP(clk.replay, clk.t0);
       }
@@ -2198,6 +2207,7 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
     mc.rows = reinterpret_cast<const h8*>(mrows);
     mc.geom = mgeom;
     mc.index = mindex;
+    mc.count = 0;
     h8 cols[R][4];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -2208,13 +2218,14 @@ __global__ __launch_bounds__(kThreads) void hook_kernel(const HookParams p) {
       const uint32_t cn = n - base < kMfmaChunk ? n - base : kMfmaChunk;
       __syncthreads();
       stage_chunk_mfma(p.scene, chunk, cn, mrows, mgeom, mindex);
+      mc.count = cn;
       __syncthreads();
       const uint32_t n_rows = base >= n_in ? 0u : (n_in - base < cn ? n_in - base : cn);
       mfma_list_always(P, mc, n_rows, cn, wl, lane, clk);
 #pragma unroll
       for (int r = 0; r < R; ++r)
         if (mfma_half_scanned(P[r])) scan_pass_mfma(P, cols[r], (uint32_t)r, mc, n_rows, wl, lane, clk);
-      replay_lists<true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index);
+      replay_lists<true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index, mc.count);
     }
     literal_world_hit(P, p.scene);
   } else if (p.accel) {

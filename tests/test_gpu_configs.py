@@ -162,6 +162,45 @@ def test_headline_frame_at_its_own_size_and_sample_count():
     scene.close()
 
 
+def test_dielectric_heavy_frame_at_1080p_1024spp():
+    """The dielectric-heavy configuration at its throughput size, 1920x1080 @ 1024 spp,
+    max_depth 50 (64 slices of 16 samples a pixel): the frame twice (same bits, same counters),
+    with the filter on the vector ALU and through the hierarchy (same bits, same ray count), a
+    strip of it rendered on its own (same bits), and every value inside the resolve's range."""
+    w, h, spp = 1920, 1080, 1024
+    world = host.create_random_world(1, (-11, 11), 0.1, 0.2, True)
+    assert len(world.spheres) == 488
+    glass = (world.materials["flags"] & abi.RT_MAT_DIELECTRIC) != 0
+    assert glass.mean() > 0.75                            # four spheres in five are glass
+    camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
+    scene = hip.Scene(world.spheres, world.materials)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def rows(r0, r1, flags):
+        out = torch.zeros((r1 - r0, w, 3), dtype=torch.float32, device="cuda:0")
+        frame = hip.make_frame(camera.m, w, h, spp, 50, 1, flags=flags)
+        hip.render_rows_device_async(scene, frame, r0, r1, True, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        return out, hip.get_stats()
+
+    full, st = rows(0, h, 0)
+    assert st.samples == w * h * spp and st.slices == 64 and st.threads_per_workgroup == 1024
+    assert st.rays > 3.3 * st.samples                     # glass keeps paths alive longer
+    again, st2 = rows(0, h, 0)
+    assert torch.equal(again.view(torch.int32), full.view(torch.int32))
+    assert (st2.rays, st2.samples) == (st.rays, st.samples)
+    for flags in (abi.RT_FLAG_SCAN_VALU, abi.RT_FLAG_ACCEL):
+        other, sto = rows(0, h, flags)
+        assert torch.equal(other.view(torch.int32), full.view(torch.int32)), flags
+        assert sto.rays == st.rays
+    strip, _ = rows(400, 440, 0)
+    assert torch.equal(strip.view(torch.int32), full[400:440].view(torch.int32))
+    img = full.cpu().numpy()
+    ok = ~np.isnan(img)
+    assert img[ok].min() >= 0.0 and img[ok].max() <= np.float32(0.999)
+    scene.close()
+
+
 def test_4k_500spp_eight_row_shares_reassemble_to_the_whole_frame():
     """3840x2160 @ 500 spp (54 slices of 9 samples and a taper of 8): the frame rendered whole,
     then as the eight shares RowPlan deals to 8 GPUs, one after the other on this GPU through the

@@ -90,6 +90,28 @@ def test_rays_from_far_outside_and_beyond_the_filters_range():
     assert strict["hit"].sum() > 100
 
 
+def test_rays_from_just_inside_the_origin_limit_do_not_pass_the_padding_rows():
+    """300 spheres leave four rows of their last block of 16, and the read-ahead block behind it,
+    without a sphere: rows that no ray may pass.  The rays that come closest to passing them are
+    those whose threshold has the most slack taken off, i.e. origins at the filter's limit, on a
+    line through the middle of the scene (nothing across the ray to add to the threshold)."""
+    rs = np.random.default_rng(31)
+    s, m = random_scene(rs, 300, (0, 0, 0), 10.0, 0.2, 2.0)
+    scene = hip.Scene(s, m)
+    limit = scene.scan_info().origin_limit
+    scene.close()
+    n = 20000
+    away = rs.normal(size=(n, 3))
+    away /= np.linalg.norm(away, axis=1, keepdims=True)
+    org = away * (limit * rs.uniform(0.96, 0.9999, size=(n, 1)))
+    tgt = rs.normal(size=(n, 3)) * 3.0
+    rays = np.zeros(n, dtype=abi.RAY_IN_DTYPE)
+    rays["ox"], rays["oy"], rays["oz"] = org.astype(np.float32).T
+    rays["dx"], rays["dy"], rays["dz"] = (tgt - org).astype(np.float32).T
+    strict, _ = three_ways(s, m, rays)
+    assert strict["hit"].sum() > 0.5 * n
+
+
 def test_zero_and_non_finite_rays_take_the_literal_loop():
     s, m = O.random_world(1, -4, 4)
     rays = np.zeros(8, dtype=abi.RAY_IN_DTYPE)

@@ -2,7 +2,9 @@
 arithmetic (STRICT_FP), the conservative scan and the hierarchy must give the same per-ray bits.
 Usage: python tools/soak_fuzz.py [n_scenes] [rays_per_kind] [first_seed]
        python tools/soak_fuzz.py images [n_scenes] [first_seed]   whole paths: per-pixel sums of
-           small frames (reference sample order, max_depth 50) in the three modes"""
+           small frames (reference sample order, max_depth 50) in the three modes
+       python tools/soak_fuzz.py grazing [n_scenes] [rays_per_scene] [first_seed]   rays within a
+           few hundred roundings of a silhouette, three filters"""
 import os
 import sys
 import time
@@ -58,9 +60,51 @@ def images():
     print("all equal: %d scenes, %d rays" % (n_scenes, rays))
 
 
+def grazing():
+    """Rays within a few hundred roundings of a silhouette (tests/test_gpu_silhouette.py's
+    generator) over random scenes at random scales: matrix filter, vector filter and literal
+    arithmetic must give the same per-ray bits."""
+    import test_gpu_silhouette as S
+    n_scenes = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    n_rays = int(sys.argv[3]) if len(sys.argv) > 3 else 500000
+    seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 5000
+    hip.init(0)
+    t0 = time.time()
+    rays_total = on_target = 0
+    for k in range(n_scenes):
+        rs = np.random.default_rng(seed0 + k)
+        n = int(rs.choice([7, 60, 300, 488, 1000, 2500]))
+        factor = float(2.0 ** rs.uniform(-12, 14))
+        s, m = F.random_scene(rs, n, (0.5, -1.0, 2.0), 10.0, 0.01, 2.0)
+        s = s.copy()
+        for f in ("x", "y", "z", "radius"):
+            s[f] = (s[f].astype(np.float64) * factor).astype(np.float32)
+        scene = hip.Scene(s, m)
+        info = scene.scan_info()
+        rays, aimed = S.grazing_rays(rs, s, n_rays, info.origin_limit if info.matrix_filter else 1e4 * factor)
+        strict = hip.trace_rays(scene, rays, seed=k, flags=abi.RT_FLAG_STRICT_FP)
+        for flags in (0, abi.RT_FLAG_SCAN_VALU):
+            got = hip.trace_rays(scene, rays, seed=k, flags=flags)
+            try:
+                F.assert_same(got, strict)
+            except AssertionError as e:
+                print("MISMATCH scene seed %d flags %d n %d factor %g: %s" % (seed0 + k, flags, n, factor, e),
+                      flush=True)
+                raise
+        scene.close()
+        rays_total += len(rays)
+        on_target += int(((strict["hit"] == 1) & (strict["sphere"] == aimed)).sum())
+        if k % 5 == 4:
+            print("%d scenes, %d grazing rays, %d of them hit the grazed sphere, %.0f s"
+                  % (k + 1, rays_total, on_target, time.time() - t0), flush=True)
+    print("all equal: %d scenes, %d grazing rays, %d hit the grazed sphere" % (n_scenes, rays_total, on_target))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "images":
         return images()
+    if len(sys.argv) > 1 and sys.argv[1] == "grazing":
+        return grazing()
     n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     n_each = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
