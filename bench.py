@@ -157,14 +157,17 @@ def drop_in_leg(hip, scene_host, camera, W, H, spp, depth, seed, steps, kernel_m
 
 
 def profiled_traffic(config, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (profiles/: FETCH_SIZE and WRITE_SIZE, in KiB, each collected in a pass of its own),
-    and where they come from.  FETCH_SIZE is doubled as the gfx950 correction for wide reads
-    prescribes, which makes the figure an upper bound for this kernel's narrow reads.
+    """Bytes per launch of `kernel` that left the L2 for memory, from the committed rocprofv3 PMC
+    passes of this same command (profiles/: FETCH_SIZE and WRITE_SIZE, in KiB, each collected in
+    a pass of its own), and where they come from.  FETCH_SIZE is doubled as the gfx950 correction
+    for wide reads prescribes, which makes the figure an upper bound for this kernel's narrow
+    reads.  The counters sit on the L2's memory side and count what the 256 MiB Infinity Cache
+    then serves as well: nearly all of this kernel's traffic is the waves' rings of parked slice
+    sums (79 MB in all for this frame), written and read back within a fraction of a millisecond.
     (None, reason) when no profile of `config` is in the tree: the counters cannot be read from
     inside a timed run."""
     import csv
-    for rnd in ("round2", "round1"):
+    for rnd in ("round3", "round2", "round1"):
         path = os.path.join(ROOT, "profiles", rnd, config + "_pmc_per_launch.csv")
         if os.path.exists(path):
             break
@@ -194,8 +197,13 @@ def profiled_issue_bound(config, kernel, kernel_ms):
     two: tools/ubench), against this run's kernel time at the nominal clock.  The lower figure
     takes SQ_INSTS_VALU to include the matrix instructions.  None without a profile."""
     import csv
-    path = os.path.join(ROOT, "profiles", "round2", config + "_pmc_per_launch.csv")
-    if not os.path.exists(path) or not kernel_ms > 0:
+    for rnd in ("round3", "round2"):
+        path = os.path.join(ROOT, "profiles", rnd, config + "_pmc_per_launch.csv")
+        if os.path.exists(path):
+            break
+    else:
+        return None
+    if not kernel_ms > 0:
         return None
     count = {}
     with open(path, newline="") as f:
@@ -355,7 +363,7 @@ def main():
         kernel_ms_source = "HIP events around each launch on its stream"
     else:
         # overlapping launches: an event pair also spans the wait for the other frame, so the
-        # per-launch time is the timed region divided by its launches (includes reduce + gather)
+        # per-launch time is the timed region divided by its launches (includes the gather)
         kernel_ms = elapsed / args.steps * 1e3
         kernel_ms_source = "timed region / launches (frames overlap, so event pairs do not isolate a launch)"
     pipelined = None

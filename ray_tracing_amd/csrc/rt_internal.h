@@ -71,7 +71,14 @@ constexpr uint32_t kChunkGrabs = RT_CHUNK_GRABS; // a workgroup's chunk of the f
 // and how many of its slices are in (one byte each).
 constexpr uint32_t kRingSlots = 32;
 constexpr size_t kSlotTableBytes = kRingSlots * sizeof(uint32_t) + kRingSlots;
-constexpr uint32_t kMergeBatch = 8;     // pixels that wait for each other before a wave merges them
+#ifndef RT_MERGE_BATCH
+#define RT_MERGE_BATCH 8
+#endif
+#ifndef RT_MERGE_EVERY
+#define RT_MERGE_EVERY 4
+#endif
+constexpr uint32_t kMergeBatch = RT_MERGE_BATCH;   // pixels that wait for each other before a wave merges them
+constexpr uint32_t kMergeEvery = RT_MERGE_EVERY;   // a wave looks for ready pixels every so many steps (a power of two)
 constexpr uint32_t kTargetItems = 1u << 20; // below this many pixels, split samples over lanes
 constexpr uint32_t kSamplesPerItem = 8;     // samples one full-size work item runs
 #ifndef RT_MAX_SLICES

@@ -1843,13 +1843,13 @@ void trace_kernel(const TraceParams p) {
   for (;;) {
     RT_MARK("refill");
     // ---- refill: next sample of the item, or the next item ------------------------------
-    // Ready pixels are merged a few at a time (the wave looks every fourth step), or at once
+    // Ready pixels are merged a few at a time (the wave looks every kMergeEvery steps), or at once
     // when the wave is about to reserve pixels and has too few free slots, or has no more work
     // to wait for.
     if (sliced) {
       const bool short_of_slots = grab_next == grab_end &&
                                   (uint32_t)__builtin_popcount(rs.free_mask) < p.grab_pixels;
-      if (short_of_slots || exhausted || (clk.steps & 3u) == 0) {
+      if (short_of_slots || exhausted || (clk.steps & (kMergeEvery - 1u)) == 0) {
         const uint32_t ready = ready_slots(st, p.slices, lane);
         if (ready != 0 && (short_of_slots || exhausted || (uint32_t)__builtin_popcount(ready) >= kMergeBatch)) {
 #ifdef RT_DIAG_PHASES
