@@ -26,8 +26,7 @@ struct rt_scene {
   mutable rt::SceneDev dev;
   void* trig = nullptr;
   void* geom = nullptr;
-  void* aux = nullptr;
-  void* mat = nullptr;
+  void* surf = nullptr;
   mutable void* bvh = nullptr;  // RT_FLAG_ACCEL: nodes, permuted geometry, original indices
   mutable void* leaf_geom = nullptr;
   mutable void* leaf_index = nullptr;
@@ -923,22 +922,18 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
 
   std::vector<float4> trig(n_spheres ? n_spheres : 1);
   std::vector<float4> geom(n_spheres ? n_spheres : 1);
-  std::vector<float2> aux(n_spheres ? n_spheres : 1);
-  std::vector<float4> mat(n_materials ? 2 * (size_t)n_materials : 2);
+  std::vector<float4> surf(n_spheres ? 2 * (size_t)n_spheres : 2);
   for (uint32_t i = 0; i < n_spheres; ++i) {
     const rt_sphere& s = spheres[i];
     volatile float r2 = s.radius * s.radius;   // `self.radius * self.radius`, src/main.rs:134
     geom[i] = make_float4(s.x, s.y, s.z, r2);
     trig[i] = make_float4(s.x, s.y, s.z, trigger_constant(s));
-    float idbits;
+    const rt_material& m = materials[s.material_id];
+    float idbits, flagbits;
     memcpy(&idbits, &s.material_id, sizeof idbits);
-    aux[i] = make_float2(s.radius, idbits);
-  }
-  for (uint32_t m = 0; m < n_materials; ++m) {
-    float flagbits;
-    memcpy(&flagbits, &materials[m].flags, sizeof flagbits);
-    mat[2 * m] = make_float4(materials[m].r, materials[m].g, materials[m].b, flagbits);
-    mat[2 * m + 1] = make_float4(materials[m].metallic_strength, materials[m].ir, 0.0f, 0.0f);
+    memcpy(&flagbits, &m.flags, sizeof flagbits);
+    surf[2 * (size_t)i] = make_float4(m.r, m.g, m.b, flagbits);
+    surf[2 * (size_t)i + 1] = make_float4(m.metallic_strength, m.ir, s.radius, idbits);
   }
   rt_scene* s = new rt_scene();
   s->device = ctx().device;
@@ -948,17 +943,14 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
   guard.s = s;
   RT_HIP(hipMalloc(&s->trig, trig.size() * sizeof(float4)));
   RT_HIP(hipMalloc(&s->geom, geom.size() * sizeof(float4)));
-  RT_HIP(hipMalloc(&s->aux, aux.size() * sizeof(float2)));
-  RT_HIP(hipMalloc(&s->mat, mat.size() * sizeof(float4)));
+  RT_HIP(hipMalloc(&s->surf, surf.size() * sizeof(float4)));
   RT_HIP(hipMemcpy(s->trig, trig.data(), trig.size() * sizeof(float4), hipMemcpyHostToDevice));
   RT_HIP(hipMemcpy(s->geom, geom.data(), geom.size() * sizeof(float4), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(s->aux, aux.data(), aux.size() * sizeof(float2), hipMemcpyHostToDevice));
-  RT_HIP(hipMemcpy(s->mat, mat.data(), mat.size() * sizeof(float4), hipMemcpyHostToDevice));
+  RT_HIP(hipMemcpy(s->surf, surf.data(), surf.size() * sizeof(float4), hipMemcpyHostToDevice));
   memset(&s->dev, 0, sizeof s->dev);
   s->dev.trig = (const float4*)s->trig;
   s->dev.geom = (const float4*)s->geom;
-  s->dev.aux = (const float2*)s->aux;
-  s->dev.mat = (const float4*)s->mat;
+  s->dev.surf = (const float4*)s->surf;
   s->dev.n_spheres = n_spheres;
   s->dev.n_materials = n_materials;
   s->dev.bvh_info = rt::BvhInfo();   // the hierarchy is built on first use (ensure_bvh)
@@ -989,8 +981,7 @@ int rt_scene_destroy(rt_scene* scene) {
   if (scene->device >= 0) (void)hipSetDevice(scene->device);
   if (scene->trig) (void)hipFree(scene->trig);
   if (scene->geom) (void)hipFree(scene->geom);
-  if (scene->aux) (void)hipFree(scene->aux);
-  if (scene->mat) (void)hipFree(scene->mat);
+  if (scene->surf) (void)hipFree(scene->surf);
   if (scene->mfma_rows) (void)hipFree(scene->mfma_rows);
   if (scene->mfma_geom) (void)hipFree(scene->mfma_geom);
   if (scene->mfma_index) (void)hipFree(scene->mfma_index);
@@ -1184,6 +1175,10 @@ int rt_get_phase_cycles(uint64_t* out16) {
     RT_HIP(hipMemcpy(&c, sl.counters, sizeof c, hipMemcpyDeviceToHost));
   }
   for (int i = 0; i < 16; ++i) out16[i] = c.phase[i];
+#ifdef RT_DIAG_DRAIN
+  // developer build: slots 0-3 carry the phases' wave-cycles after the waves ran out of work
+  for (int i = 0; i < 4; ++i) out16[i] = c.phase[16 + i];
+#endif
 #ifdef RT_DIAG_RING
   // developer build: slots 8-11 carry the waves' open-pixel statistics instead of drain steps
   // (steps starved of slots, path slots idle in them, merges, pixels merged)

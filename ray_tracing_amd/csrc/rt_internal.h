@@ -144,8 +144,8 @@ inline void set_tile_width(TileDev& t, uint32_t w) {
 //   trig[i] = (cx, cy, cz, -k'/2)               read by every ray for every sphere; k' is
 //             |c|^2 - r^2 minus a rounding slack (see trigger_constant in rt_api.cpp)
 //   geom[i] = (cx, cy, cz, radius*radius)       read when a sphere is replayed exactly
-//   aux[i]  = (radius, material_id bits)        read once per hit
-//   mat[2m] = (r, g, b, flags bits), mat[2m+1] = (metallic_strength, ir, 0, 0)
+//   surf[2i] = (r, g, b, flags bits), surf[2i+1] = (metallic_strength, ir, radius, material_id
+//             bits): the sphere's radius and a copy of its material, read once per hit
 // Optional bounding-volume hierarchy (RT_FLAG_ACCEL; built by build_bvh in rt_bvh.cpp).
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 struct BvhNode {
@@ -173,8 +173,7 @@ void build_bvh(const rt_sphere* spheres, uint32_t n, BvhHost* out);
 struct SceneDev {
   const float4* trig;
   const float4* geom;
-  const float2* aux;
-  const float4* mat;
+  const float4* surf;
   uint32_t n_spheres;
   uint32_t n_materials;
   // RT_FLAG_ACCEL

@@ -98,6 +98,7 @@ struct PhaseClock {
   unsigned long long starved_steps, starved_idle;   // steps a wave could not reserve pixels for
                                                     // want of slots; path slots left idle in them
   unsigned long long merges, merged_pixels;         // calls of merge_ready, pixels they wrote
+  unsigned long long at_exhaustion[4];              // refill, scan, replay, shade when the wave ran out of work
 };
 
 #ifndef RT_MIN_WAVES
@@ -306,12 +307,13 @@ struct Bounce {
 __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, float inv_len, float t,
                                             uint32_t sphere, PathRng& rng) {
   Bounce b;
+  // (the sphere's radius and its material's fields sit in one record per sphere: a hit costs one
+  // round trip to memory, not one for the material's number and another for the material)
   const float4 g = sc.geom[sphere];
-  const float2 aux = sc.aux[sphere];
-  const float radius = aux.x;
-  b.material = __float_as_uint(aux.y);
-  const float4 m0 = sc.mat[2 * b.material];
-  const float4 m1 = sc.mat[2 * b.material + 1];
+  const float4 m0 = sc.surf[2 * sphere];
+  const float4 m1 = sc.surf[2 * sphere + 1];
+  const float radius = m1.z;
+  b.material = __float_as_uint(m1.w);
   const uint32_t flags = __float_as_uint(m0.w);
   const V3 color = mk(m0.x, m0.y, m0.z);
 
@@ -578,7 +580,18 @@ __device__ __forceinline__ bool candidate_root(float4 s, V3 o, V3 d, float a, fl
 // COLLECT = false leaves the paths' best hits in the keys (wl.keys_live) instead of taking them
 // back into registers, for a replay in the middle of a scan pass: the pass's loop then changes no
 // path state, and the replay that ends the step starts from those keys and collects.
-template <bool PERM = false, bool COLLECT = true>
+// COMPACT: the wave's live paths are numbered 0, 1, ... in the order (slot 0 of every lane, then
+// slot 1), and the entries, the published rays and the keys go by those numbers (compact_slot);
+// paths that are not alive publish and collect nothing.
+__device__ __forceinline__ uint32_t compact_slot(const Path (&P)[R], int r) {
+  const unsigned long long m0 = __builtin_amdgcn_ballot_w64(P[0].alive);
+  if (r == 0) return __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+  const unsigned long long m1 = __builtin_amdgcn_ballot_w64(P[1].alive);
+  return (uint32_t)__builtin_popcountll(m0) +
+         __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+}
+
+template <bool PERM = false, bool COLLECT = true, bool COMPACT = false>
 __device__ __forceinline__ void replay_lists(Path (&P)[R], const float4* sph, const float* sr2,
                                              uint32_t chunk_base, WaveLists& wl, uint32_t lane,
                                              PhaseClock& clk, const uint32_t* index = nullptr,
@@ -587,16 +600,22 @@ __device__ __forceinline__ void replay_lists(Path (&P)[R], const float4* sph, co
   // wave-uniform: every lane reads the same word
   const bool keys_live = __builtin_amdgcn_readfirstlane((int)wl.counter[1]) != 0;
   if (n == 0 && !(COLLECT && keys_live)) return;
+  // (formed here, where the whole wave is: compact_slot counts the live paths of all lanes)
+  uint32_t where[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) where[r] = COMPACT ? compact_slot(P, r) : (uint32_t)r * kWave + lane;
   if (n != 0) {
 #ifdef RT_DIAG_PHASES
     if (lane == 0) clk.cand += n;   // summed over lanes at the end
 #endif
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint32_t slot = (uint32_t)r * kWave + lane;
-      wl.rays[2 * slot] = make_float4(P[r].ox, P[r].oy, P[r].oz, P[r].a);
-      wl.rays[2 * slot + 1] = make_float4(P[r].dx, P[r].dy, P[r].dz, 0.0f);
-      if (!keys_live) wl.keys[slot] = P[r].best == kNone ? kNoHit : hit_key(P[r].closest, P[r].best);
+      const uint32_t slot = where[r];
+      if (!COMPACT || P[r].alive) {
+        wl.rays[2 * slot] = make_float4(P[r].ox, P[r].oy, P[r].oz, P[r].a);
+        wl.rays[2 * slot + 1] = make_float4(P[r].dx, P[r].dy, P[r].dz, 0.0f);
+        if (!keys_live) wl.keys[slot] = P[r].best == kNone ? kNoHit : hit_key(P[r].closest, P[r].best);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -628,7 +647,8 @@ __device__ __forceinline__ void replay_lists(Path (&P)[R], const float4* sph, co
   if (COLLECT) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const unsigned long long mine = wl.keys[(uint32_t)r * kWave + lane];
+      if (COMPACT && !P[r].alive) continue;
+      const unsigned long long mine = wl.keys[where[r]];
       if (mine != kNoHit) {
         P[r].closest = __uint_as_float((uint32_t)(mine >> 32));
         P[r].best = 0xFFFFFFFFu - (uint32_t)mine;
@@ -890,6 +910,55 @@ __device__ __forceinline__ void mfma_prepare_half(const Path& P, float scale, h8
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The same for a wave that has no more work to wait for and at most 16 NB live paths: their
+// columns go to the places compact_slot numbers them by, whichever lane and path slot they sit
+// in, so that NB ray blocks (NB products per 16 spheres instead of eight) cover them all.  The
+// places of the last block that no path takes get the column that passes no row.
+template <int NB>
+__device__ __forceinline__ void mfma_prepare_compact(const Path (&P)[R], float scale, h8* stage,
+                                                     uint32_t lane, h8 (&b)[NB]) {
+  const uint32_t c = lane & 15, g = lane >> 4;
+  uint32_t where[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) where[r] = compact_slot(P, r);
+  uint32_t live = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) live += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(P[r].alive));
+  if (lane >= live && lane < 16u * NB) {
+    h8 q[4];
+    mfma_ray_column(P[0], false, scale, q);
+    const uint32_t sw = ((c >> 1) + (c >> 3)) & 3u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) stage[lane * 4 + ((uint32_t)k ^ sw)] = q[k];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (P[r].alive) {
+      h8 q[4];
+      mfma_ray_column(P[r], true, scale, q);
+      const uint32_t cc = where[r] & 15u;
+      const uint32_t sw = ((cc >> 1) + (cc >> 3)) & 3u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) stage[where[r] * 4 + ((uint32_t)k ^ sw)] = q[k];
+    }
+  }
+  const uint32_t sw = ((c >> 1) + (c >> 3)) & 3u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int jj = 0; jj < NB; ++jj) b[jj] = stage[(16 * jj + c) * 4 + (g ^ sw)];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef RT_COMPACT_BLOCKS
+#define RT_COMPACT_BLOCKS 1
+#endif
+constexpr int kCompactBlocks = RT_COMPACT_BLOCKS > 0 ? RT_COMPACT_BLOCKS : 1;
+constexpr uint32_t kCompactPaths = 16u * RT_COMPACT_BLOCKS;   // 0: never
+
 // What a chunk looks like in LDS for the matrix scan.
 struct MfmaChunk {
   const h8* rows;          // [4][kMfmaRows]: quarter q of the sphere at position i at rows[q * kMfmaRows + i]
@@ -943,7 +1012,10 @@ __device__ __forceinline__ void mfma_test_always(Path (&P)[R], const MfmaChunk& 
 // One pass over the chunk's rows for one half of the wave's paths (path slot `half` of every
 // lane; b = mfma_prepare_half's columns).  Sixteen results per lane at a time, for 16 spheres x
 // 64 paths; thirty-two at a time (both halves) does not fit the register budget.
-__device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], uint32_t half,
+// NB < 4 with COMPACT: the wave's live paths, numbered by compact_slot, fill the first NB ray
+// blocks (mfma_prepare_compact), `half` is 0 and an entry names a path by that number.
+template <int NB = 4, bool COMPACT = false>
+__device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[NB], uint32_t half,
                                                const MfmaChunk& m, uint32_t n_rows, WaveLists& wl,
                                                uint32_t lane, PhaseClock& clk) {
   const uint32_t c = lane & 15, g = lane >> 4;
@@ -953,9 +1025,9 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], u
   __hip_atomic_store(wl.counter, wl.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
   h8 a = m.rows[g * kMfmaRows + c];
   for (uint32_t blk = 0; blk < n_rows; blk += kMfmaBlock) {
-    f4v acc[4];
+    f4v acc[NB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], zero, 0, 0, 0);
+    for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], zero, 0, 0, 0);
     a = m.rows[g * kMfmaRows + blk + kMfmaBlock + c];   // read ahead (the rows are padded by a block)
     // Result i of ray block j is v[4 i + j]: sphere blk + 4 g + i against the path in slot
     // 64 half + 16 j + c.  A float that is not negative is an integer that is not negative:
@@ -964,11 +1036,18 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], u
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[4 * i + j] = __float_as_int(acc[j][i]);
+      for (int i = 0; i < 4; ++i) v[4 * i + j] = j < NB ? __float_as_int(acc[j < NB ? j : 0][i]) : -1;
     int top = v[0];
+    if (NB == 4) {
 #pragma unroll
-    for (int k = 1; k + 1 < 16; k += 2) top = max(max(top, v[k]), v[k + 1]);
-    top = max(top, v[15]);
+      for (int k = 1; k + 1 < 16; k += 2) top = max(max(top, v[k]), v[k + 1]);
+      top = max(top, v[15]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) top = max(top, v[4 * i + j]);
+    }
 #ifdef RT_DIAG_PHASES
     clk.blocks++;
 #endif
@@ -1026,7 +1105,7 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[4], u
         wl.count = L;
         RT_STAMP(clk.scan, clk.t0);
         RT_PRIO_REST();
-        replay_lists<true, false>(P, m.geom, nullptr, 0, wl, lane, clk, m.index, m.count);
+        replay_lists<true, false, COMPACT>(P, m.geom, nullptr, 0, wl, lane, clk, m.index, m.count);
         RT_STAMP(clk.replay, clk.t0);
         RT_PRIO_MFMA();
         __hip_atomic_store(wl.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1832,6 +1911,7 @@ void trace_kernel(const TraceParams p) {
   }
   uint32_t grab_next = 0, grab_end = 0;
   bool exhausted = false;
+  bool idle = false;   // no path of the wave was alive at the last look (wave-uniform)
   unsigned long long n_rays = 0, n_samples = 0;   // of the wave (wave-uniform)
   uint32_t bvh_interior = 0, bvh_tests = 0;   // diagnostic build: nodes opened, spheres tested
   PhaseClock clk = {};
@@ -1844,14 +1924,15 @@ void trace_kernel(const TraceParams p) {
     RT_MARK("refill");
     // ---- refill: next sample of the item, or the next item ------------------------------
     // Ready pixels are merged a few at a time (the wave looks every kMergeEvery steps), or at once
-    // when the wave is about to reserve pixels and has too few free slots, or has no more work
-    // to wait for.
+    // when the wave is about to reserve pixels and has too few free slots, or has no live path
+    // left.  (A merge is seven round trips to the ring in a row: a wave that merged every pixel as
+    // it became ready while its last paths ran paid that latency in most of those steps.)
     if (sliced) {
       const bool short_of_slots = grab_next == grab_end &&
                                   (uint32_t)__builtin_popcount(rs.free_mask) < p.grab_pixels;
-      if (short_of_slots || exhausted || (clk.steps & (kMergeEvery - 1u)) == 0) {
+      if (short_of_slots || idle || (clk.steps & (kMergeEvery - 1u)) == 0) {
         const uint32_t ready = ready_slots(st, p.slices, lane);
-        if (ready != 0 && (short_of_slots || exhausted || (uint32_t)__builtin_popcount(ready) >= kMergeBatch)) {
+        if (ready != 0 && (short_of_slots || idle || (uint32_t)__builtin_popcount(ready) >= kMergeBatch)) {
 #ifdef RT_DIAG_PHASES
           clk.merges++;
           clk.merged_pixels += (uint32_t)__builtin_popcount(ready);
@@ -1903,7 +1984,8 @@ void trace_kernel(const TraceParams p) {
     // A wave that found the workgroup's range empty while another wave was fetching the next
     // chunk goes round too, and asks again.
     const bool pending = (sliced && rs.free_mask != all_slots) || rs.waiting;
-    const bool wave_alive = __builtin_amdgcn_ballot_w64(any_alive) != 0 || pending;
+    idle = __builtin_amdgcn_ballot_w64(any_alive) == 0;
+    const bool wave_alive = !idle || pending;
     if (MULTI) {
       if (!__syncthreads_or(wave_alive ? 1 : 0)) break;   // workgroup-uniform
     } else {
@@ -1930,7 +2012,13 @@ void trace_kernel(const TraceParams p) {
     }
     // Out of work and nearly drained: trace what is left spheres-across-lanes (tail_hit).
     // Zero or non-finite rays keep to the scan, whose replay has the literal fallback.
-    bool tail = false;
+    bool tail = false, compact = false;
+#ifdef RT_DIAG_DRAIN
+    if (exhausted && clk.t_exhausted == 0) {
+      clk.at_exhaustion[0] = clk.refill; clk.at_exhaustion[1] = clk.scan;
+      clk.at_exhaustion[2] = clk.replay; clk.at_exhaustion[3] = clk.shade;
+    }
+#endif
 #ifdef RT_DIAG_PHASES
     if (exhausted && clk.t_exhausted == 0) clk.t_exhausted = __builtin_amdgcn_s_memtime();
 #endif
@@ -1943,6 +2031,8 @@ void trace_kernel(const TraceParams p) {
         odd = odd || (P[r].alive && P[r].degenerate);
       }
       tail = live <= (MFMA ? kTailPathsMfma : kTailPaths) && __builtin_amdgcn_ballot_w64(odd) == 0;
+      // (matrix filter, one chunk) few enough paths for one ray block: see mfma_prepare_compact
+      compact = MFMA && !MULTI && !tail && live <= kCompactPaths && __builtin_amdgcn_ballot_w64(odd) == 0;
     }
     if constexpr (ACCEL) {
       if (p.bvh_in_lds) bvh_hit<true>(P[0], p.scene, bvh_src, bvh_stack, bvh_interior, bvh_tests);
@@ -1976,6 +2066,13 @@ void trace_kernel(const TraceParams p) {
             RT_STAMP(clk.replay, clk.t0);
           }
         }
+      } else if (compact) {
+        mfma_test_always(P, mc, n_in, n);
+        h8 cols[kCompactBlocks];
+        mfma_prepare_compact<kCompactBlocks>(P, p.scene.mfma_scale, stage, lane, cols);
+        scan_pass_mfma<kCompactBlocks, true>(P, cols, 0u, mc, n_in, wl, lane, clk);
+        replay_lists<true, true, true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index, mc.count);
+        RT_STAMP(clk.replay, clk.t0);
       } else if (!tail) {
         // one chunk: a half's columns are built right before its pass, so that only four
         // operands (16 VGPRs) are alive at a time
@@ -2073,14 +2170,15 @@ void trace_kernel(const TraceParams p) {
   RT_MARK("epilogue");
 
 #ifdef RT_DIAG_PHASES
+  [[maybe_unused]] const unsigned long long t_end_of_wave = __builtin_amdgcn_s_memtime();
+  if (clk.t_exhausted == 0) clk.t_exhausted = t_end_of_wave;   // never out of work while it had paths
   if (lane == 0) {
     atomicAdd(&p.counters->phase[0], clk.refill);
     atomicAdd(&p.counters->phase[1], clk.scan);
     atomicAdd(&p.counters->phase[2], clk.replay);
     atomicAdd(&p.counters->phase[3], clk.shade);
     atomicAdd(&p.counters->phase[4], clk.steps);
-    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-    if (clk.t_exhausted == 0) clk.t_exhausted = t_end;
+    const unsigned long long t_end = t_end_of_wave;
     atomicAdd(&p.counters->phase[5], t_end - clk.t_exhausted);   // drain time, summed over waves
     atomicMax(&p.counters->phase[6], t_end - clk.t_exhausted);   // longest drain
     atomicMax(&p.counters->phase[7], t_end - clk.t_start);       // longest-lived wave
@@ -2093,6 +2191,16 @@ void trace_kernel(const TraceParams p) {
 #endif
     atomicAdd(&p.counters->phase[13], 1ull);                     // waves
   }
+#ifdef RT_DIAG_DRAIN
+  // a build for reading where a wave's time goes after it ran out of work: wave-cycles per phase
+  // from that moment on, summed over waves
+  if (lane == 0 && clk.t_exhausted != t_end_of_wave) {
+    atomicAdd(&p.counters->phase[16], clk.refill - clk.at_exhaustion[0]);
+    atomicAdd(&p.counters->phase[17], clk.scan - clk.at_exhaustion[1]);
+    atomicAdd(&p.counters->phase[18], clk.replay - clk.at_exhaustion[2]);
+    atomicAdd(&p.counters->phase[19], clk.shade - clk.at_exhaustion[3]);
+  }
+#endif
 #ifdef RT_DIAG_RING
   if (lane == 0) {
     atomicAdd(&p.counters->phase[16], clk.starved_steps);

@@ -1,3 +1,7 @@
+"""Developer tool: what the waves do after the frame's work runs out, on one rank's eighth of the
+1080p frame.  Load a diagnostic build: RT_HIP_LIB=ray_tracing_amd/librt_hip_diag.so (phase shares,
+drain steps) or librt_hip_diagdrain.so (the phases' wave-cycles inside the drain).
+Usage: python tools/drain_probe.py [flags]"""
 import sys, numpy as np, torch
 spp = 100
 import os
@@ -24,7 +28,11 @@ ph = hip.get_phase_cycles().astype(np.float64)
 waves = max(ph[13], 1)
 print("kernel %.3f ms, steps/wave %.1f" % (st.kernel_ms, ph[4] / waves))
 tot = ph[:4].sum()
-print("shares refill %.1f scan %.1f replay %.1f shade %.1f" % tuple(100 * ph[i] / tot for i in range(4)))
+if "diagdrain" not in os.environ.get("RT_HIP_LIB", ""):
+    print("shares refill %.1f scan %.1f replay %.1f shade %.1f" % tuple(100 * ph[i] / tot for i in range(4)))
 print("drain: mean %.0f kcyc  longest %.0f kcyc  longest-lived wave %.0f kcyc" % (ph[5] / waves / 1e3, ph[6] / 1e3, ph[7] / 1e3))
 print("drain steps that scanned: mean %.1f max %.0f; tail steps: mean %.1f max %.0f; cycles per tail step %.0f"
       % (ph[8] / waves, ph[10], ph[9] / waves, ph[11], ph[12] / max(ph[9], 1)))
+if "diagdrain" in os.environ.get("RT_HIP_LIB", ""):
+    print("drain kcycles per wave: refill %.0f  hit %.0f  replay %.0f  shade %.0f"
+          % (ph[0] / waves / 1e3, ph[1] / waves / 1e3, ph[2] / waves / 1e3, ph[3] / waves / 1e3))
