@@ -1178,6 +1178,14 @@ int rt_get_phase_cycles(uint64_t* out16) {
 #ifdef RT_DIAG_DRAIN
   // developer build: slots 0-3 carry the phases' wave-cycles after the waves ran out of work
   for (int i = 0; i < 4; ++i) out16[i] = c.phase[16 + i];
+  // slots 8-11: first and last wave out of work, last wave's end, counted from the first wave's start
+  {
+    const uint64_t start = ~c.phase[20];
+    out16[8] = ~c.phase[21] - start;
+    out16[9] = c.phase[22] - start;
+    out16[10] = c.phase[23] - start;
+    out16[11] = c.phase[15];   // most steps a wave took after it ran out of work
+  }
 #endif
 #ifdef RT_DIAG_RING
   // developer build: slots 8-11 carry the waves' open-pixel statistics instead of drain steps

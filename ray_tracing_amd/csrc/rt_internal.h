@@ -198,7 +198,7 @@ struct Counters {
   unsigned long long samples;  // shoot_ray calls from the pixel loop
   // Wave-cycles per phase and drain statistics (see rt_get_phase_cycles); filled only by a
   // build with -DRT_DIAG_PHASES, whose timings are for shares, not for speed.
-  unsigned long long phase[20];   // 16-18: see RT_DIAG_TRIGGERS in rt_kernels.hip
+  unsigned long long phase[24];   // 16-23: see RT_DIAG_TRIGGERS, RT_DIAG_RING, RT_DIAG_DRAIN in rt_kernels.hip
 };
 
 struct TraceParams {

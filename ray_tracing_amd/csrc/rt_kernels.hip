@@ -99,6 +99,7 @@ struct PhaseClock {
                                                     // want of slots; path slots left idle in them
   unsigned long long merges, merged_pixels;         // calls of merge_ready, pixels they wrote
   unsigned long long at_exhaustion[4];              // refill, scan, replay, shade when the wave ran out of work
+  unsigned long long real_start, real_exhausted;    // 100 MHz clock
 };
 
 #ifndef RT_MIN_WAVES
@@ -1919,6 +1920,9 @@ void trace_kernel(const TraceParams p) {
   clk.t0 = __builtin_amdgcn_s_memtime();
   clk.t_start = clk.t0;
 #endif
+#ifdef RT_DIAG_DRAIN
+  clk.real_start = __builtin_amdgcn_s_memrealtime();
+#endif
 
   for (;;) {
     RT_MARK("refill");
@@ -2017,6 +2021,7 @@ void trace_kernel(const TraceParams p) {
     if (exhausted && clk.t_exhausted == 0) {
       clk.at_exhaustion[0] = clk.refill; clk.at_exhaustion[1] = clk.scan;
       clk.at_exhaustion[2] = clk.replay; clk.at_exhaustion[3] = clk.shade;
+      clk.real_exhausted = __builtin_amdgcn_s_memrealtime();
     }
 #endif
 #ifdef RT_DIAG_PHASES
@@ -2200,6 +2205,16 @@ void trace_kernel(const TraceParams p) {
     atomicAdd(&p.counters->phase[18], clk.replay - clk.at_exhaustion[2]);
     atomicAdd(&p.counters->phase[19], clk.shade - clk.at_exhaustion[3]);
   }
+  // and when the waves started, ran out of work and ended, by the constant 100 MHz clock all
+  // compute units share (complements, where the earliest is wanted: the counters start at zero)
+  if (clk.real_exhausted == 0) clk.real_exhausted = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) {
+    atomicMax(&p.counters->phase[20], ~clk.real_start);
+    atomicMax(&p.counters->phase[21], ~clk.real_exhausted);
+    atomicMax(&p.counters->phase[22], clk.real_exhausted);
+    atomicMax(&p.counters->phase[23], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    atomicMax(&p.counters->phase[15], clk.drain_scan_steps + clk.tail_steps);   // most steps after the work ran out
+  }
 #endif
 #ifdef RT_DIAG_RING
   if (lane == 0) {
@@ -2225,10 +2240,14 @@ void trace_kernel(const TraceParams p) {
     // the hierarchy's counts, or (scan) queued candidates and 64 x the replay loop's trips
     const unsigned long long bi = ACCEL ? wave_sum(bvh_interior) : wave_sum((uint32_t)clk.cand);
     const unsigned long long bt = ACCEL ? wave_sum(bvh_tests) : clk.replay_iters * 64ull;
+#ifndef RT_DIAG_DRAIN
     if (lane == 0) {
       atomicAdd(&p.counters->phase[14], bi);                     // hierarchy: interior nodes opened
       atomicAdd(&p.counters->phase[15], bt);                     // hierarchy: leaf spheres tested
     }
+#else
+    (void)bi; (void)bt;
+#endif
   }
 #endif
   if (lane == 0) {

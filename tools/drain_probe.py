@@ -31,8 +31,12 @@ tot = ph[:4].sum()
 if "diagdrain" not in os.environ.get("RT_HIP_LIB", ""):
     print("shares refill %.1f scan %.1f replay %.1f shade %.1f" % tuple(100 * ph[i] / tot for i in range(4)))
 print("drain: mean %.0f kcyc  longest %.0f kcyc  longest-lived wave %.0f kcyc" % (ph[5] / waves / 1e3, ph[6] / 1e3, ph[7] / 1e3))
-print("drain steps that scanned: mean %.1f max %.0f; tail steps: mean %.1f max %.0f; cycles per tail step %.0f"
-      % (ph[8] / waves, ph[10], ph[9] / waves, ph[11], ph[12] / max(ph[9], 1)))
+if "diagdrain" not in os.environ.get("RT_HIP_LIB", ""):
+    print("drain steps that scanned: mean %.1f max %.0f; tail steps: mean %.1f max %.0f; cycles per tail step %.0f"
+          % (ph[8] / waves, ph[10], ph[9] / waves, ph[11], ph[12] / max(ph[9], 1)))
+else:
+    print("from the first wave's start: first wave out of work at %.3f ms, last at %.3f ms, last wave ends at %.3f ms; "
+          "most steps a wave took after it ran out of work: %d" % (ph[8] / 1e5, ph[9] / 1e5, ph[10] / 1e5, ph[11]))
 if "diagdrain" in os.environ.get("RT_HIP_LIB", ""):
     print("drain kcycles per wave: refill %.0f  hit %.0f  replay %.0f  shade %.0f"
           % (ph[0] / waves / 1e3, ph[1] / waves / 1e3, ph[2] / waves / 1e3, ph[3] / waves / 1e3))
