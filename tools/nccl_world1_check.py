@@ -27,8 +27,11 @@ frame = hip.make_frame(cam.m, W, H, 8, 50, 1, 0)
 plan = multi_gpu.RowPlan(W, H, 1)
 streams = [torch.cuda.Stream(device=device) for _ in range(2)]
 frames = []
+shardeds = []   # kept until the streams are drained: a buffer freed while its stream still works on it
+                # would be handed to the next frame by torch's caching allocator
 for k in range(4):
     sharded = multi_gpu.ShardedFrame(plan, device, 0)
+    shardeds.append(sharded)
     with torch.cuda.stream(streams[k % 2]):
         raw = streams[k % 2].cuda_stream
 
