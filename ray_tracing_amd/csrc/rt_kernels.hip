@@ -114,6 +114,9 @@ constexpr int U = kScanUnroll;
 // hit found so far, as a key that an integer minimum orders like World::hit does (smaller t
 // first, the later sphere at equal t), and the paths' rays (origin, a / direction), published
 // there for the replay, whose lanes test candidates of paths that other lanes own.
+#ifndef RT_SCAN_FOLD
+#define RT_SCAN_FOLD 1
+#endif
 constexpr uint32_t L = kListEntries;
 constexpr uint32_t kSlots = (uint32_t)(R * kWave);
 static_assert(R == 2, "an entry keeps the path slot in 7 bits: lane | r << 6");
@@ -488,14 +491,26 @@ __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&
   }
   // the literal form compares the discriminant with zero, as the reference does
   unsigned long long m[NB][R], hot[R];
+  constexpr bool kFold = !STRICT && NB > 1 && RT_SCAN_FOLD != 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const float thr = STRICT ? 0.0f : P[r].thr;
     hot[r] = 0;
+    if (kFold) {
+      // One compare per path and block: the largest of the block's values against the path's
+      // threshold (the conservative form never yields a NaN for a ray the scan lists: its terms
+      // are finite and the only infinity it can reach is +inf, from hb'^2).  The masks per
+      // sphere are formed in the rare block that has a candidate.
+      float top = v[0][r];
 #pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      m[u][r] = __builtin_amdgcn_ballot_w64(!(v[u][r] < thr));
-      hot[r] |= m[u][r];
+      for (int u = 1; u < NB; ++u) top = __builtin_fmaxf(top, v[u][r]);
+      hot[r] = __builtin_amdgcn_ballot_w64(!(top < thr));
+    } else {
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        m[u][r] = __builtin_amdgcn_ballot_w64(!(v[u][r] < thr));
+        hot[r] |= m[u][r];
+      }
     }
     hot[r] &= ok[r];
   }
@@ -509,6 +524,12 @@ __device__ __forceinline__ void test_block(const float4 (&s)[NB], const float (&
 #ifdef RT_DIAG_PHASES
     clk.trig_blocks++;
 #endif
+    if (kFold) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int u = 0; u < NB; ++u) m[u][r] = __builtin_amdgcn_ballot_w64(!(v[u][r] < P[r].thr));
+    }
     // All further decisions are the scalar unit's, and only a pair that has a candidate (two
     // of the eight, typically, with a single lane each) costs vector instructions: a ballot
     // count gives every such lane its place behind the list's end.
