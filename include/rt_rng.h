@@ -1,4 +1,5 @@
-/* Counter-based random stream shared by the HIP kernels, the C++ host mirror and the CPU oracle.
+/* Keyed random stream shared by the HIP kernels, the C++ host mirror and the CPU oracle (called
+ * the counter stream elsewhere: every sample's draws are a function of counters, not of history).
  *
  * The reference draws every random number from rand::random::<f32>() (src/cpu/job.rs:50-51,
  * src/main.rs:215,267-269): a thread-local, OS-seeded ChaCha12 stream mapped to
@@ -8,10 +9,19 @@
  * (seed, pixel index, sample index, draw number).  A render is then bit-reproducible for any
  * tiling, any lane assignment and any number of GPUs.
  *
- * stream(seed, pixel, sample):   state0 = mix(mix(mix(seed ^ A) ^ pixel) + sample)
+ * stream(seed, pixel, sample):   state0 = mix(mix(mix(seed ^ A) ^ pixel) + sample)   (never 0)
  *                                inc    = mix(mix(mix(seed + B) + pixel) ^ sample) | 1
- * draw number c (0-based):       bits = mix(state0 + (c + 1) * inc);  xi = (bits >> 8) * 2^-24
- * mix() is the 32-bit finaliser "lowbias32" (two multiplies, three xor-shifts).
+ * draw number c (0-based):       bits = x(c + 1) + inc, with x(0) = state0 and x(k + 1) = the
+ *                                xorshift32 step (13, 17, 5) of x(k);  xi = (bits >> 8) * 2^-24
+ * mix() is the 32-bit finaliser "lowbias32" (two multiplies, three xor-shifts).  It seeds every
+ * sample's stream; the draws inside a sample come from the shift-and-xor recurrence, because a
+ * 32-bit integer multiply runs at a quarter of the vector ALU's rate on the GPU and a path makes
+ * four draws per segment (one hash per draw: about 1 % of the benchmark frame's time).  Marsaglia's
+ * xorshift32 has the full period 2^32 - 1 over non-zero states; `inc` keeps the streams of two
+ * samples that meet on that cycle from handing out the same values.
+ *
+ * Scene construction (the reference's create_random_world draws from the same rand::random)
+ * uses the counter form, bits = mix(state0 + (c + 1) * inc): rt_rng_counter_next_*.
  */
 #ifndef RT_RNG_H
 #define RT_RNG_H
@@ -48,6 +58,7 @@ RT_HD uint32_t rt_rng_pixel_b(uint32_t seed_b, uint32_t pixel) { return rt_mix32
 RT_HD rt_rng rt_rng_from_pixel(uint32_t pixel_a, uint32_t pixel_b, uint32_t sample) {
   rt_rng r;
   r.state = rt_mix32(pixel_a + sample);
+  if (r.state == 0U) r.state = 0x9E3779B9U; /* the one state the shift-and-xor recurrence cannot leave */
   r.inc = rt_mix32(pixel_b ^ sample) | 1U;
   return r;
 }
@@ -58,13 +69,26 @@ RT_HD rt_rng rt_rng_init(uint32_t seed, uint32_t pixel, uint32_t sample) {
 }
 
 RT_HD uint32_t rt_rng_next_u32(rt_rng* r) {
-  r->state += r->inc;
-  return rt_mix32(r->state);
+  uint32_t x = r->state;
+  x ^= x << 13;
+  x ^= x >> 17;
+  x ^= x << 5;
+  r->state = x;
+  return x + r->inc;
 }
 
 /* Same mapping as rand 0.8.5's Standard distribution for f32: 24 random bits * 2^-24. */
 RT_HD float rt_rng_next_f32(rt_rng* r) {
   return (float)(rt_rng_next_u32(r) >> 8) * (1.0f / 16777216.0f);
+}
+
+/* The counter form, for scene construction. */
+RT_HD uint32_t rt_rng_counter_next_u32(rt_rng* r) {
+  r->state += r->inc;
+  return rt_mix32(r->state);
+}
+RT_HD float rt_rng_counter_next_f32(rt_rng* r) {
+  return (float)(rt_rng_counter_next_u32(r) >> 8) * (1.0f / 16777216.0f);
 }
 
 /* Pixel index reserved for streams that are not tied to a pixel (scene construction). */

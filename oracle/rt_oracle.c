@@ -49,6 +49,7 @@ void ro_rng_counter(ro_rng* r, uint32_t seed, uint32_t pixel, uint32_t sample) {
   r->script_len = 0;
   r->draws = 0;
   r->chacha = NULL;
+  r->scene = pixel == RT_RNG_SCENE_STREAM;
 }
 
 void ro_rng_scripted(ro_rng* r, const float* values, uint32_t n) {
@@ -57,6 +58,7 @@ void ro_rng_scripted(ro_rng* r, const float* values, uint32_t n) {
   r->script_len = n;
   r->draws = 0;
   r->chacha = NULL;
+  r->scene = 0;
 }
 
 void ro_rng_chacha(ro_rng* r, ro_chacha* generator) {
@@ -65,6 +67,7 @@ void ro_rng_chacha(ro_rng* r, ro_chacha* generator) {
   r->script_len = 0;
   r->draws = 0;
   r->chacha = generator;
+  r->scene = 0;
 }
 
 float ro_random_f32(ro_rng* r) {
@@ -73,6 +76,8 @@ float ro_random_f32(ro_rng* r) {
     v = ro_chacha12_next_f32(r->chacha);
   } else if (r->script != NULL && r->draws < r->script_len) {
     v = r->script[r->draws];
+  } else if (r->scene) {
+    v = rt_rng_counter_next_f32(&r->counter);
   } else {
     v = rt_rng_next_f32(&r->counter);
   }

@@ -66,7 +66,8 @@ uint32_t ro_chacha12_next_u32(ro_chacha* c);
 float ro_chacha12_next_f32(ro_chacha* c);
 
 /* Source of "rand::random::<f32>()" values.  Three kinds:
- *   counter  : the rt_rng.h stream (shared with the GPU)
+ *   counter  : the rt_rng.h stream (shared with the GPU): a sample's draws, or, for the stream
+ *              RT_RNG_SCENE_STREAM, the draws of scene construction
  *   scripted : values read from an array, for known-answer tests; counts what it hands out
  *   chacha   : a ChaCha12 generator that outlives the ro_rng (one per worker, like the
  *              reference's thread-local generator), independent of rt_rng.h */
@@ -76,6 +77,7 @@ typedef struct ro_rng {
   uint32_t script_len;
   uint32_t draws; /* number of values handed out so far */
   ro_chacha* chacha;
+  uint32_t scene; /* counter kind: the scene-construction form of the stream (rt_rng_counter_next_f32) */
 } ro_rng;
 
 void ro_rng_counter(ro_rng* r, uint32_t seed, uint32_t pixel, uint32_t sample);

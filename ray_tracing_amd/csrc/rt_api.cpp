@@ -88,6 +88,7 @@ struct LaunchSlot {
   rt::Counters* counters = nullptr;       // device
   float* ring = nullptr;                  // device: the waves' parked slice sums (grow-only;
   size_t ring_cap = 0;                    // fixed for the no-alloc slot), capacity in floats
+  size_t ring_stride = 0;                 // floats per wave in the slot's last launch
   uint64_t last_use = 0;
   rt_stats last = {};
   uint64_t launch_no = 0;                 // 1-based number of the slot's last launch; 0 = none
@@ -722,6 +723,7 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
       slot->ring_cap = need;
     }
     p.ring = slot->ring;
+    slot->ring_stride = (size_t)p.ring_slots * per_slot;
   }
 
   // the counters must start at zero; the rings need no clearing (a parked sum is read only
@@ -1162,6 +1164,24 @@ int rt_get_stats(rt_stats* out) {
   *out = s;
   return RT_OK;
 }
+
+#ifdef RT_DIAG_DRAIN
+// Developer build only (not part of the ABI): the record every wave of the last launch left at
+// the start of its ring (see the epilogue of trace_kernel), 16 words per wave.
+extern "C" int rt_debug_wave_log(uint64_t* out, uint32_t max_waves, uint32_t* n_waves) {
+  ApiScope scope;
+  if (int rc = check_ready()) return rc;
+  if (!ctx().last_slot || !ctx().last_slot->ring) return fail(RT_ERR_INVALID_ARGUMENT, "no sliced launch yet");
+  const LaunchSlot& sl = *ctx().last_slot;
+  RT_HIP(hipStreamSynchronize(sl.stream));
+  const uint32_t waves = sl.last.workgroups * (sl.last.threads_per_workgroup / rt::kWave);
+  const size_t stride = sl.ring_stride;   // floats per wave
+  *n_waves = waves < max_waves ? waves : max_waves;
+  for (uint32_t w = 0; w < *n_waves; ++w)
+    RT_HIP(hipMemcpy(out + 16 * (size_t)w, sl.ring + stride * w, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+#endif
 
 int rt_get_phase_cycles(uint64_t* out16) {
   ApiScope scope;

@@ -87,10 +87,20 @@ namespace {
 #define RT_PRIO_REST() __builtin_amdgcn_s_setprio(RT_PRIO_REST_LEVEL)
 #define RT_PRIO_MFMA() __builtin_amdgcn_s_setprio(RT_PRIO_MFMA_LEVEL)
 
+// The lane's number again, through a statement the compiler cannot look into or move: what is
+// computed from the result (LDS addresses of the lane's places in the wave's lists, mostly) is
+// computed where it is used, a few instructions, instead of once before the main loop - from
+// where, the registers being full, it would be spilled to scratch memory and read back with a
+// round trip to device memory in the middle of a step.
+__device__ __forceinline__ uint32_t here(uint32_t lane) {
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
 struct PhaseClock {
   unsigned long long t0, refill, scan, replay, shade, steps;
   unsigned long long t_start, t_exhausted, tail_steps;
-  unsigned long long drain_scan_steps, tail_cycles;
+  unsigned long long drain_scan_steps, tail_cycles, compact_steps;
   unsigned long long cand, replay_iters;   // queued candidates (per lane), replay loop trips (per wave)
   unsigned long long trig_cycles, prep_cycles;   // diagnostic: inside the candidate code, building columns
   unsigned long long blocks, trig_blocks, trig_pairs;   // scan blocks, those that branched to the
@@ -912,9 +922,10 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v);
 // (the published rays of the replay; the candidate list may hold entries already).
 __device__ __forceinline__ void mfma_prepare_half(const Path& P, float scale, h8* stage, uint32_t lane,
                                                   h8 (&b)[4]) {
-  const uint32_t c = lane & 15, g = lane >> 4;
   h8 q[4];
   mfma_ray_column(P, P.alive && !P.degenerate, scale, q);
+  lane = here(lane);   // (the eight swizzled addresses below were spilled and read back one by one)
+  const uint32_t c = lane & 15, g = lane >> 4;
   // A column is 64 bytes, so lanes that follow each other would all start in the same two
   // banks: quarter k of ray l sits at place k ^ sw(l) of its column instead, with sw chosen so
   // that any 8 (or 16) consecutive rays spread one quarter over all 32 (or 64) banks, on the
@@ -2150,6 +2161,7 @@ void trace_kernel(const TraceParams p) {
 #ifdef RT_DIAG_PHASES
     if (tail) clk.tail_steps++;
     else if (exhausted) clk.drain_scan_steps++;
+    if (compact) clk.compact_steps++;
     if (tail) clk.tail_cycles += __builtin_amdgcn_s_memtime() - clk.t0;
 #endif
 
@@ -2235,6 +2247,25 @@ void trace_kernel(const TraceParams p) {
     atomicMax(&p.counters->phase[22], clk.real_exhausted);
     atomicMax(&p.counters->phase[23], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     atomicMax(&p.counters->phase[15], clk.drain_scan_steps + clk.tail_steps);   // most steps after the work ran out
+    // and a record per wave at the start of its own ring (free by now: every open pixel is
+    // merged), for rt_debug_wave_log: started, out of work, ended (100 MHz clock), cycles and
+    // steps after the work ran out, and the phases' cycles in that time
+    if (p.slices != 1) {
+      unsigned long long* rec = reinterpret_cast<unsigned long long*>(p.ring + ring_offset(p));
+      rec[0] = clk.real_start;
+      rec[1] = clk.real_exhausted;
+      rec[2] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+      rec[3] = t_end_of_wave - clk.t_exhausted;
+      rec[4] = clk.drain_scan_steps;
+      rec[5] = clk.tail_steps;
+      rec[6] = clk.steps;
+      rec[7] = clk.compact_steps;
+      rec[8] = clk.refill - clk.at_exhaustion[0];
+      rec[9] = clk.scan - clk.at_exhaustion[1];
+      rec[10] = clk.replay - clk.at_exhaustion[2];
+      rec[11] = clk.shade - clk.at_exhaustion[3];
+      rec[12] = clk.tail_cycles;
+    }
   }
 #endif
 #ifdef RT_DIAG_RING

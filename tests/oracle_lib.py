@@ -51,7 +51,7 @@ class Chacha(C.Structure):
 
 class Rng(C.Structure):
     _fields_ = [("counter", RtRng), ("script", C.POINTER(C.c_float)), ("script_len", C.c_uint32),
-                ("draws", C.c_uint32), ("chacha", C.POINTER(Chacha))]
+                ("draws", C.c_uint32), ("chacha", C.POINTER(Chacha)), ("scene", C.c_uint32)]
 
 
 class Counters(C.Structure):

@@ -280,8 +280,12 @@ def test_body_and_taper_slices_agree_with_the_reference_sample_order():
     tapered tail (4,4,2,2,1,1,1,1), against the same frame with every pixel's samples added in
     the reference's order (`pixel_color += color`, src/cpu/job.rs:58).  The paths are the same
     (equal ray counts), so the two sums of n = 300 floats differ only by the association of the
-    additions: each is within (n-1) u of the exact sum relative to the sum of magnitudes
-    (u = 2^-24), so they are within 2 n u = 3.6e-5 of each other; the test prints what it finds."""
+    additions: each is within (n-1) u of the exact sum relative to the sum of the terms'
+    magnitudes (u = 2^-24), so they are within 2 n u = 3.6e-5 of that sum of each other.  The sum
+    of magnitudes is not known per pixel: it is at most n (a sample's radiance is a product of
+    albedos, below 1 in magnitude, and the sky) and about the pixel's sum itself wherever no
+    negative albedo makes the terms cancel, so the bound proper is asserted against n and the
+    bulk of the pixels (median, 99.9 %) against the pixel's own sum; the test prints what it finds."""
     w, h, spp = 1920, 1080, 300
     world = host.create_random_world(1, (-11, 11))
     camera = host.Camera.new((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, w / h)
@@ -304,6 +308,7 @@ def test_body_and_taper_slices_agree_with_the_reference_sample_order():
     err = np.abs(a - b) / scale
     print("sliced vs sequential sums, relative difference: max %.3g, median %.3g, 99.9%% %.3g"
           % (err.max(), np.median(err), np.quantile(err, 0.999)))
-    assert err.max() <= 2 * spp * 2.0 ** -24
+    assert np.abs(a - b).max() <= 2 * spp * 2.0 ** -24 * spp
+    assert np.quantile(err, 0.999) <= 2 * spp * 2.0 ** -24
     assert np.median(err) <= 2e-6
     scene.close()

@@ -314,6 +314,20 @@ def test_counter_stream_matches_python_restatement():
     b = mix((seed + 0x632BE5AB) & 0xFFFFFFFF)
     state = mix((mix(a ^ pixel) + sample) & 0xFFFFFFFF)
     inc = mix(mix((b + pixel) & 0xFFFFFFFF) ^ sample) | 1
+    # a sample's draws: the xorshift32 recurrence (13, 17, 5) from the hashed state, offset by inc
+    assert state != 0
+    rng = O.counter_rng(seed, pixel, sample)
+    x = state
+    for _ in range(16):
+        x ^= (x << 13) & 0xFFFFFFFF
+        x ^= x >> 17
+        x ^= (x << 5) & 0xFFFFFFFF
+        expect = (((x + inc) & 0xFFFFFFFF) >> 8) / 2.0 ** 24
+        assert O.lib().ro_random_f32(C.byref(rng)) == expect
+    # scene construction (the stream RT_RNG_SCENE_STREAM): the counter form, one hash per draw
+    pixel, sample = 0xFFFFFFF1, 0
+    state = mix((mix(a ^ pixel) + sample) & 0xFFFFFFFF)
+    inc = mix(mix((b + pixel) & 0xFFFFFFFF) ^ sample) | 1
     rng = O.counter_rng(seed, pixel, sample)
     for _ in range(16):
         state = (state + inc) & 0xFFFFFFFF

@@ -11,6 +11,7 @@ Usage: python tools/rank_share_bench.py [rank] [spp] [reps] [frames_in_flight] [
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -60,10 +61,11 @@ def main():
         st = hip.get_stats()
         if base is None:
             base = wall
+        crc = zlib.crc32(outs[0].cpu().numpy().tobytes())   # the same for every build of the library
         line = ("N=%d rank %d: %3d row blocks, kernel %.2f ms (min %.2f), wall/step %.2f ms, "
-                "rays/sample %.3f, ideal %.2f ms, scaling if all ranks alike %.2fx"
+                "rays/sample %.3f, ideal %.2f ms, scaling if all ranks alike %.2fx, crc %08x"
                 % (n, rank, len(tiles), ms.mean(), ms.min(), wall, st.rays / max(st.samples, 1),
-                   base / n, base / wall))
+                   base / n, base / wall, crc))
         ph = hip.get_phase_cycles()
         if ph[4]:
             waves = max(1, int(ph[13]))
