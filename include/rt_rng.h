@@ -10,18 +10,20 @@
  * tiling, any lane assignment and any number of GPUs.
  *
  * stream(seed, pixel, sample):   state0 = mix(mix(mix(seed ^ A) ^ pixel) + sample)   (never 0)
- *                                inc    = mix(mix(mix(seed + B) + pixel) ^ sample) | 1
+ *                                inc    = (state0 rotated right by 11 bits) ^ B | 1
  * draw number c (0-based):       bits = x(c + 1) + inc, with x(0) = state0 and x(k + 1) = the
  *                                xorshift32 step (13, 17, 5) of x(k);  xi = (bits >> 8) * 2^-24
  * mix() is the 32-bit finaliser "lowbias32" (two multiplies, three xor-shifts).  It seeds every
- * sample's stream; the draws inside a sample come from the shift-and-xor recurrence, because a
- * 32-bit integer multiply runs at a quarter of the vector ALU's rate on the GPU and a path makes
- * four draws per segment (one hash per draw: about 1 % of the benchmark frame's time).  Marsaglia's
- * xorshift32 has the full period 2^32 - 1 over non-zero states; `inc` keeps the streams of two
- * samples that meet on that cycle from handing out the same values.
+ * sample's stream - one hash per pixel and one per sample; the draws inside a sample come from
+ * the shift-and-xor recurrence, because a 32-bit integer multiply runs at a quarter of the vector
+ * ALU's rate on the GPU and a path makes four draws per segment (one hash per draw, and four
+ * per sample: about 2 % of the benchmark frame's time).  Marsaglia's xorshift32 has the full
+ * period 2^32 - 1 over non-zero states; `inc` keeps the streams of two samples that meet on that
+ * cycle from handing out the same values (their draws differ by a constant modulo 1).
  *
  * Scene construction (the reference's create_random_world draws from the same rand::random)
- * uses the counter form, bits = mix(state0 + (c + 1) * inc): rt_rng_counter_next_*.
+ * uses the counter form: state0 as above, inc = mix(mix(mix(seed + B) + pixel) ^ sample) | 1,
+ * bits = mix(state0 + (c + 1) * inc): rt_rng_counter_init, rt_rng_counter_next_*.
  */
 #ifndef RT_RNG_H
 #define RT_RNG_H
@@ -48,24 +50,21 @@ RT_HD uint32_t rt_mix32(uint32_t x) {
   return x;
 }
 
-/* Per-render constants: computed once, not per sample. */
+/* Per-render constant: computed once, not per sample. */
 RT_HD uint32_t rt_rng_seed_a(uint32_t seed) { return rt_mix32(seed ^ 0xA511E9B3U); }
-RT_HD uint32_t rt_rng_seed_b(uint32_t seed) { return rt_mix32(seed + 0x632BE5ABU); }
-/* Per-pixel constants: computed once per pixel. */
-RT_HD uint32_t rt_rng_pixel_a(uint32_t seed_a, uint32_t pixel) { return rt_mix32(seed_a ^ pixel); }
-RT_HD uint32_t rt_rng_pixel_b(uint32_t seed_b, uint32_t pixel) { return rt_mix32(seed_b + pixel); }
+/* Per-pixel constant: computed once per pixel (or per work item). */
+RT_HD uint32_t rt_rng_pixel(uint32_t seed_a, uint32_t pixel) { return rt_mix32(seed_a ^ pixel); }
 
-RT_HD rt_rng rt_rng_from_pixel(uint32_t pixel_a, uint32_t pixel_b, uint32_t sample) {
+RT_HD rt_rng rt_rng_from_pixel(uint32_t pixel_hash, uint32_t sample) {
   rt_rng r;
-  r.state = rt_mix32(pixel_a + sample);
+  r.state = rt_mix32(pixel_hash + sample);
   if (r.state == 0U) r.state = 0x9E3779B9U; /* the one state the shift-and-xor recurrence cannot leave */
-  r.inc = rt_mix32(pixel_b ^ sample) | 1U;
+  r.inc = (((r.state >> 11) | (r.state << 21)) ^ 0x632BE5ABU) | 1U;
   return r;
 }
 
 RT_HD rt_rng rt_rng_init(uint32_t seed, uint32_t pixel, uint32_t sample) {
-  return rt_rng_from_pixel(rt_rng_pixel_a(rt_rng_seed_a(seed), pixel),
-                           rt_rng_pixel_b(rt_rng_seed_b(seed), pixel), sample);
+  return rt_rng_from_pixel(rt_rng_pixel(rt_rng_seed_a(seed), pixel), sample);
 }
 
 RT_HD uint32_t rt_rng_next_u32(rt_rng* r) {
@@ -83,6 +82,12 @@ RT_HD float rt_rng_next_f32(rt_rng* r) {
 }
 
 /* The counter form, for scene construction. */
+RT_HD rt_rng rt_rng_counter_init(uint32_t seed, uint32_t pixel, uint32_t sample) {
+  rt_rng r;
+  r.state = rt_mix32(rt_mix32(rt_rng_seed_a(seed) ^ pixel) + sample);
+  r.inc = rt_mix32(rt_mix32(rt_mix32(seed + 0x632BE5ABU) + pixel) ^ sample) | 1U;
+  return r;
+}
 RT_HD uint32_t rt_rng_counter_next_u32(rt_rng* r) {
   r->state += r->inc;
   return rt_mix32(r->state);

@@ -44,12 +44,12 @@ static inline ro_vec3 v3_cross(ro_vec3 a, ro_vec3 b) {
  * 267-269, 342-361)
  * ---------------------------------------------------------------------------------------- */
 void ro_rng_counter(ro_rng* r, uint32_t seed, uint32_t pixel, uint32_t sample) {
-  r->counter = rt_rng_init(seed, pixel, sample);
+  r->scene = pixel == RT_RNG_SCENE_STREAM;
+  r->counter = r->scene ? rt_rng_counter_init(seed, pixel, sample) : rt_rng_init(seed, pixel, sample);
   r->script = NULL;
   r->script_len = 0;
   r->draws = 0;
   r->chacha = NULL;
-  r->scene = pixel == RT_RNG_SCENE_STREAM;
 }
 
 void ro_rng_scripted(ro_rng* r, const float* values, uint32_t n) {

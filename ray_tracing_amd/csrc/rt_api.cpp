@@ -544,7 +544,6 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   p.max_depth = frame->max_depth;
   p.spp = frame->samples_per_pixel;
   p.seed_a = rt_rng_seed_a(frame->seed);
-  p.seed_b = rt_rng_seed_b(frame->seed);
   uint32_t slice_begin[rt::kMaxSlices + 1];
   p.slices = plan_slices(*frame, slice_begin);
   for (uint32_t k = 0; k <= p.slices; ++k) p.slice_begin[k] = sample_begin + slice_begin[k];

@@ -207,7 +207,7 @@ struct TraceParams {
   float origin[3];        // view_inv * (0,0,0,1), a per-frame constant (src/main.rs:71-72)
   uint32_t width, height;
   uint32_t max_depth, spp;
-  uint32_t seed_a, seed_b;  // rt_rng_seed_a/b(seed)
+  uint32_t seed_a;          // rt_rng_seed_a(seed)
   uint32_t slices;          // work items per pixel; item = pixel * slices + slice
   Divider slices_div;       // division by slices
   uint32_t grab_pixels;     // pixels a wave reserves at a time from its workgroup's chunk

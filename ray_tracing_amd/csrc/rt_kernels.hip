@@ -412,7 +412,7 @@ struct Path {
   bool has_item;
   float ar, ag, ab; // running sum of the item's samples
   float fx, fy;     // pixel coordinates as f32
-  uint32_t pixel;   // y * W + x
+  uint32_t pixel;   // rt_rng_pixel(seed, y * W + x): the hash that seeds the streams of the pixel's samples
   uint32_t out_index;
   uint32_t sample, sample_end;
 };
@@ -1673,7 +1673,7 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, uint32_t slot
   }
   P.fx = (float)px;
   P.fy = (float)py;
-  P.pixel = py * p.width + px;
+  P.pixel = rt_rng_pixel(p.seed_a, py * p.width + px);   // what the pixel's number is wanted for
   // Where the item's sum goes: the pixel's place in the output (below 2^32: checked on the
   // host), or, with sliced samples, entry `sl` of the pixel's slot in the wave's ring; the lane
   // that runs a pixel's first slice notes where the pixel goes.
@@ -1699,8 +1699,7 @@ __device__ __forceinline__ void setup_item(Path& P, uint32_t item, uint32_t slot
 // Camera::get_ray (src/main.rs:70-83, Mat4*Vec4 = ((c0*x + c1*y) + c2*z) + c3*w).
 template <bool LEAN = false>
 __device__ __forceinline__ void start_sample(Path& P, const TraceParams& p) {
-  P.rng.g = rt_rng_from_pixel(rt_rng_pixel_a(p.seed_a, P.pixel), rt_rng_pixel_b(p.seed_b, P.pixel),
-                              P.sample);
+  P.rng.g = rt_rng_from_pixel(P.pixel, P.sample);
   P.rng.draws = 0;
   float u = (P.fx + next_f32(P.rng)) / (float)p.width;
   float v = (P.fy + next_f32(P.rng)) / (float)p.height;

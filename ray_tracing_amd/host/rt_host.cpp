@@ -96,7 +96,7 @@ Mat4 inverse(const Mat4& in) {
 // Sequential draws of scene construction: the stream (seed, RT_RNG_SCENE_STREAM, 0).
 struct SceneRng {
   rt_rng g;
-  explicit SceneRng(uint32_t seed) : g(rt_rng_init(seed, RT_RNG_SCENE_STREAM, 0)) {}
+  explicit SceneRng(uint32_t seed) : g(rt_rng_counter_init(seed, RT_RNG_SCENE_STREAM, 0)) {}
   float next() { return rt_rng_counter_next_f32(&g); }  // rand::random::<f32>()
   Vec3 vec3() {                                         // random_vec3, src/main.rs:266-271
     const float x = next() * 2.0f - 1.0f;

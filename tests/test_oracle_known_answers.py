@@ -313,9 +313,9 @@ def test_counter_stream_matches_python_restatement():
     a = mix(seed ^ 0xA511E9B3)
     b = mix((seed + 0x632BE5AB) & 0xFFFFFFFF)
     state = mix((mix(a ^ pixel) + sample) & 0xFFFFFFFF)
-    inc = mix(mix((b + pixel) & 0xFFFFFFFF) ^ sample) | 1
     # a sample's draws: the xorshift32 recurrence (13, 17, 5) from the hashed state, offset by inc
     assert state != 0
+    inc = (((state >> 11) | (state << 21)) & 0xFFFFFFFF) ^ 0x632BE5AB | 1
     rng = O.counter_rng(seed, pixel, sample)
     x = state
     for _ in range(16):
