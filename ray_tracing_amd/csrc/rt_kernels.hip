@@ -986,8 +986,17 @@ __device__ __forceinline__ void mfma_prepare_compact(const Path (&P)[R], float s
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef RT_LEND
+#define RT_LEND 1   // out of work, an item's last sample is lent to an idle path slot (lend_samples)
+#endif
+#ifndef RT_DRAIN_BLOCKS
+#define RT_DRAIN_BLOCKS 4   // blocks of spheres per trip of the one-ray-block pass (scan_pass_mfma, SB)
+#endif
+#ifndef RT_COMPACT_TIERS
+#define RT_COMPACT_TIERS 1   // one ray block for up to 16 live paths, RT_COMPACT_BLOCKS beyond
+#endif
 #ifndef RT_COMPACT_BLOCKS
-#define RT_COMPACT_BLOCKS 1
+#define RT_COMPACT_BLOCKS 4
 #endif
 constexpr int kCompactBlocks = RT_COMPACT_BLOCKS > 0 ? RT_COMPACT_BLOCKS : 1;
 constexpr uint32_t kCompactPaths = 16u * RT_COMPACT_BLOCKS;   // 0: never
@@ -1047,31 +1056,54 @@ __device__ __forceinline__ void mfma_test_always(Path (&P)[R], const MfmaChunk& 
 // 64 paths; thirty-two at a time (both halves) does not fit the register budget.
 // NB < 4 with COMPACT: the wave's live paths, numbered by compact_slot, fill the first NB ray
 // blocks (mfma_prepare_compact), `half` is 0 and an entry names a path by that number.
-template <int NB = 4, bool COMPACT = false>
+// SB > 1 (with NB = 1 and COMPACT): SB blocks of spheres per trip against the one ray block, their
+// rows read a trip ahead.  A wave that is out of work takes its steps one after the other with
+// little else on its SIMD to fill the gaps, and a trip of one product - wait for the rows, the
+// product, the fold, the branch - is a chain of some 230 cycles, 31 times over; four products in
+// a row and one fold and branch for the four make it eight chains of that length (a step of a
+// lone wave with 8 paths: 5.07 -> 4.15 us).
+template <int NB = 4, bool COMPACT = false, int SB = 1>
 __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[NB], uint32_t half,
                                                const MfmaChunk& m, uint32_t n_rows, WaveLists& wl,
                                                uint32_t lane, PhaseClock& clk) {
+  static_assert(SB == 1 || (NB == 1 && COMPACT && SB <= 4), "several sphere blocks per trip: one ray block only");
   const uint32_t c = lane & 15, g = lane >> 4;
   RT_MARK("scan");
   RT_PRIO_MFMA();
   const f4v zero = {0.0f, 0.0f, 0.0f, 0.0f};
   __hip_atomic_store(wl.counter, wl.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  h8 a = m.rows[g * kMfmaRows + c];
-  for (uint32_t blk = 0; blk < n_rows; blk += kMfmaBlock) {
-    f4v acc[NB];
+  // (the rows behind the chunk's spheres, up to and including the block of padding, pass no ray:
+  // a trip may run over the end of the spheres, and the read-ahead stops at the padding)
+  h8 a[SB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[j], zero, 0, 0, 0);
-    a = m.rows[g * kMfmaRows + blk + kMfmaBlock + c];   // read ahead (the rows are padded by a block)
+  for (int s = 0; s < SB; ++s) a[s] = m.rows[g * kMfmaRows + (uint32_t)s * kMfmaBlock + c];
+  for (uint32_t blk = 0; blk < n_rows; blk += kMfmaBlock * SB) {
+    f4v acc[NB * SB];
+    if (SB == 1) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[j], zero, 0, 0, 0);
+      a[0] = m.rows[g * kMfmaRows + blk + kMfmaBlock + c];   // read ahead (the rows are padded by a block)
+    } else {
+#pragma unroll
+      for (int s = 0; s < SB; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], b[0], zero, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < SB; ++s) {
+        const uint32_t ahead = blk + (uint32_t)(SB + s) * kMfmaBlock;
+        a[s] = m.rows[g * kMfmaRows + (ahead < kMfmaChunk ? ahead : kMfmaChunk) + c];
+      }
+    }
     // Result i of ray block j is v[4 i + j]: sphere blk + 4 g + i against the path in slot
-    // 64 half + 16 j + c.  A float that is not negative is an integer that is not negative:
-    // the maximum of the 16 as integers says whether this lane has any candidate at all.
+    // 64 half + 16 j + c (SB > 1: of sphere block j, sphere blk + 16 j + 4 g + i against path c).
+    // A float that is not negative is an integer that is not negative: the maximum of the 16 as
+    // integers says whether this lane has any candidate at all.
+    constexpr int NJ = NB * SB;
     int v[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[4 * i + j] = j < NB ? __float_as_int(acc[j < NB ? j : 0][i]) : -1;
+      for (int i = 0; i < 4; ++i) v[4 * i + j] = j < NJ ? __float_as_int(acc[j < NJ ? j : 0][i]) : -1;
     int top = v[0];
-    if (NB == 4) {
+    if (NJ == 4) {
 #pragma unroll
       for (int k = 1; k + 1 < 16; k += 2) top = max(max(top, v[k]), v[k + 1]);
       top = max(top, v[15]);
@@ -1079,7 +1111,7 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[NB], 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) top = max(top, v[4 * i + j]);
+        for (int j = 0; j < NJ; ++j) top = max(top, v[4 * i + j]);
     }
 #ifdef RT_DIAG_PHASES
     clk.blocks++;
@@ -1107,6 +1139,10 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[NB], 
       asm volatile("" : "+v"(zero));
       const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
       const uint32_t base = (blk << 7) | (half << 6) | ((ln >> 4) << 9) | (ln & 15u);
+      // bit 8 i + j of the mask: sphere + i, and ray block j (16 path slots) or sphere block j
+      const auto entry_offset = [](uint32_t q) {
+        return SB == 1 ? q << 4 : ((q >> 3) << 7) | ((q & 7u) << 11);
+      };
       for (;;) {
         // A lane with candidates reserves its run of the list with one LDS atomic on the list's
         // length (the order of the entries does not matter to the replay).
@@ -1122,7 +1158,7 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[NB], 
           while (cand != 0) {
             const uint32_t q = (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1;
-            *dst++ = base + (q << 4);
+            *dst++ = base + entry_offset(q);
           }
           break;
         }
@@ -1132,7 +1168,7 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[NB], 
         while (cand != 0 && at < L) {
           const uint32_t q = (uint32_t)__builtin_ctz(cand);
           cand &= cand - 1;
-          wl.list[at] = base + (q << 4);
+          wl.list[at] = base + entry_offset(q);
           ++at;
         }
         wl.count = L;
@@ -1811,6 +1847,121 @@ __device__ __forceinline__ void merge_ready(uint32_t ready, const TraceParams& p
   else merge_pixels_call(ready, ring_wave, p.slices, p.out, (lds_u32*)st.out_at, mode, p.inv_spp);
 }
 
+// ---- out of work: an item's last sample is run by an idle path slot of the wave ---------------
+// When the frame's work has run out, what holds a wave (and with the last wave, the launch) is
+// its longest chain of dependent steps, and an item of several samples is such a chain twice
+// over: a path that runs max_depth segments, and then the item's next sample, which may do the
+// same.  So once the wave is out of work, an item that still has a sample to come after the one
+// it is running LENDS its last sample to a path slot of the wave that has nothing left to do.
+// The borrower runs the sample from a sum of zero and holds the result; when the lender has
+// finished the samples it kept, it adds the borrowed sample's sum - after its own, as the last
+// term, which is where `pixel_color += color` (src/cpu/job.rs:58) adds that sample - and writes
+// the item.  Same bits as without: 0 + x is x for every x but -0, which the sum turns into +0
+// either way.  One loan per item at a time; the two sides know each other by path slot number
+// (lane | slot << 6), kept in spare bits of out_index (sliced samples only: slot << 8 | slice).
+constexpr uint32_t kLent = 0x80000000u;       // this item waits for a borrowed sample: bits 16-22 = the borrower
+constexpr uint32_t kBorrowed = 0x40000000u;   // this slot runs a borrowed sample: bits 0-6 = the lender
+__device__ __forceinline__ uint32_t rank_in(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Borrowed samples that are finished go back to lenders that are finished.  `xch`: 4 KB of the
+// wave's LDS that nothing uses during the refill (the published rays of the replay).
+__device__ __forceinline__ void return_loans(Path (&P)[R], uint32_t* xch, uint32_t lane) {
+  unsigned long long ready[R], done[R];
+  bool fin[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    fin[r] = P[r].has_item && !P[r].alive && P[r].sample >= P[r].sample_end;
+    ready[r] = __builtin_amdgcn_ballot_w64(fin[r] && (P[r].out_index & kLent) != 0);
+    done[r] = __builtin_amdgcn_ballot_w64(fin[r] && (P[r].out_index & kBorrowed) != 0);
+  }
+  if ((ready[0] | ready[1]) == 0 || (done[0] | done[1]) == 0) return;
+  float* fx = reinterpret_cast<float*>(xch);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (fin[r] && (P[r].out_index & kBorrowed) != 0) {
+      const uint32_t o = P[r].out_index & 127u;
+      const unsigned long long m = (o & 64u) ? ready[1] : ready[0];
+      if ((m >> (o & 63u)) & 1ull) {
+        fx[4 * o] = P[r].ar; fx[4 * o + 1] = P[r].ag; fx[4 * o + 2] = P[r].ab;
+        P[r].has_item = false;
+        P[r].out_index = 0;
+      }
+    }
+  }
+  wave_sync_lds();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (fin[r] && (P[r].out_index & kLent) != 0) {
+      const uint32_t b = (P[r].out_index >> 16) & 127u;
+      const unsigned long long m = (b & 64u) ? done[1] : done[0];
+      if ((m >> (b & 63u)) & 1ull) {
+        const uint32_t self = lane | ((uint32_t)r << 6);
+        P[r].ar += fx[4 * self]; P[r].ag += fx[4 * self + 1]; P[r].ab += fx[4 * self + 2];
+        P[r].out_index &= 0xFFFFu;
+      }
+    }
+  }
+  wave_sync_lds();
+}
+// Items with a sample still to come after the one they are running lend it to idle path slots.
+__device__ __forceinline__ void lend_samples(Path (&P)[R], uint32_t* xch, uint32_t lane) {
+  bool don[R], tak[R];
+  unsigned long long md[R], mt[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    don[r] = P[r].alive && P[r].has_item && (P[r].out_index >> 30) == 0 && P[r].sample + 1 < P[r].sample_end;
+    tak[r] = !P[r].alive && !P[r].has_item;
+    md[r] = __builtin_amdgcn_ballot_w64(don[r]);
+    mt[r] = __builtin_amdgcn_ballot_w64(tak[r]);
+  }
+  const uint32_t nd = (uint32_t)(__builtin_popcountll(md[0]) + __builtin_popcountll(md[1]));
+  const uint32_t nt = (uint32_t)(__builtin_popcountll(mt[0]) + __builtin_popcountll(mt[1]));
+  const uint32_t n = nd < nt ? nd : nt;
+  if (n == 0) return;
+  uint32_t rd[R], rk[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    rd[r] = (r ? (uint32_t)__builtin_popcountll(md[0]) : 0u) + rank_in(md[r]);
+    rk[r] = (r ? (uint32_t)__builtin_popcountll(mt[0]) : 0u) + rank_in(mt[r]);
+    const uint32_t self = lane | ((uint32_t)r << 6);
+    if (don[r] && rd[r] < n) {
+      uint32_t* rec = xch + 8 * rd[r];
+      rec[0] = P[r].pixel;
+      rec[1] = __float_as_uint(P[r].fx);
+      rec[2] = __float_as_uint(P[r].fy);
+      rec[3] = P[r].sample_end - 1u;
+      rec[4] = self;
+    }
+    if (tak[r] && rk[r] < n) xch[8 * rk[r] + 5] = self;
+  }
+  wave_sync_lds();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (don[r] && rd[r] < n) {
+      P[r].sample_end -= 1u;
+      P[r].out_index |= kLent | (xch[8 * rd[r] + 5] << 16);
+    }
+    if (tak[r] && rk[r] < n) {
+      const uint32_t* rec = xch + 8 * rk[r];
+      P[r].pixel = rec[0];
+      P[r].fx = __uint_as_float(rec[1]);
+      P[r].fy = __uint_as_float(rec[2]);
+      P[r].sample = rec[3];
+      P[r].sample_end = rec[3] + 1u;
+      P[r].out_index = kBorrowed | rec[4];
+      P[r].ar = P[r].ag = P[r].ab = 0.0f;
+      P[r].has_item = true;
+    }
+  }
+  wave_sync_lds();
+}
+
 [[maybe_unused]] __device__ __forceinline__ unsigned long long wave_sum(uint32_t v) {
   unsigned long long s = v;
 #pragma unroll
@@ -1978,10 +2129,15 @@ void trace_kernel(const TraceParams p) {
     }
     rs.starved = false;
     rs.waiting = false;
+    if constexpr (!ACCEL && RT_LEND != 0) {
+      if (exhausted && sliced) return_loans(P, reinterpret_cast<uint32_t*>(wl.rays), lane);
+    }
 #pragma unroll
     for (int r = 0; r < RP; ++r) {
       const bool need = !P[r].alive && P[r].sample >= P[r].sample_end;
-      if (need && P[r].has_item) {
+      // (an item that waits for a borrowed sample, or is one, is not written: see lend_samples)
+      const bool on_loan = !ACCEL && RT_LEND != 0 && sliced && (P[r].out_index >> 30) != 0;
+      if (need && P[r].has_item && !on_loan) {
         write_item(P[r], p, st);
         P[r].has_item = false;
       }
@@ -2000,8 +2156,11 @@ void trace_kernel(const TraceParams p) {
       // Out of work: a lane whose first path slot is finished takes its second slot's path into
       // the first.  The wave's last paths then sit in slot 0 (unless a lane still has two), and
       // everything a step does per slot - a pass of the matrix scan, the shading - is done once.
+      if (RT_LEND != 0 && exhausted && sliced) lend_samples(P, reinterpret_cast<uint32_t*>(wl.rays), lane);
       if (exhausted) {
-        const bool move = !P[0].alive && !P[0].has_item && P[1].alive;
+        // (a path that lent or borrowed a sample is known to its partner by its slot and stays)
+        const bool move = !P[0].alive && !P[0].has_item && P[1].alive &&
+                          !(RT_LEND != 0 && sliced && (P[1].out_index >> 30) != 0);
         if (move) {
           P[0] = P[1];
           P[1].alive = false;
@@ -2048,6 +2207,7 @@ void trace_kernel(const TraceParams p) {
     // Out of work and nearly drained: trace what is left spheres-across-lanes (tail_hit).
     // Zero or non-finite rays keep to the scan, whose replay has the literal fallback.
     bool tail = false, compact = false;
+    [[maybe_unused]] bool few = false;
 #ifdef RT_DIAG_DRAIN
     if (exhausted && clk.t_exhausted == 0) {
       clk.at_exhaustion[0] = clk.refill; clk.at_exhaustion[1] = clk.scan;
@@ -2069,6 +2229,7 @@ void trace_kernel(const TraceParams p) {
       tail = live <= (MFMA ? kTailPathsMfma : kTailPaths) && __builtin_amdgcn_ballot_w64(odd) == 0;
       // (matrix filter, one chunk) few enough paths for one ray block: see mfma_prepare_compact
       compact = MFMA && !MULTI && !tail && live <= kCompactPaths && __builtin_amdgcn_ballot_w64(odd) == 0;
+      few = live <= 16u;
     }
     if constexpr (ACCEL) {
       if (p.bvh_in_lds) bvh_hit<true>(P[0], p.scene, bvh_src, bvh_stack, bvh_interior, bvh_tests);
@@ -2104,9 +2265,18 @@ void trace_kernel(const TraceParams p) {
         }
       } else if (compact) {
         mfma_test_always(P, mc, n_in, n);
-        h8 cols[kCompactBlocks];
-        mfma_prepare_compact<kCompactBlocks>(P, p.scene.mfma_scale, stage, lane, cols);
-        scan_pass_mfma<kCompactBlocks, true>(P, cols, 0u, mc, n_in, wl, lane, clk);
+#if RT_COMPACT_TIERS
+        if (few) {   // one ray block
+          h8 cols[1];
+          mfma_prepare_compact<1>(P, p.scene.mfma_scale, stage, lane, cols);
+          scan_pass_mfma<1, true, RT_DRAIN_BLOCKS>(P, cols, 0u, mc, n_in, wl, lane, clk);
+        } else
+#endif
+        {
+          h8 cols[kCompactBlocks];
+          mfma_prepare_compact<kCompactBlocks>(P, p.scene.mfma_scale, stage, lane, cols);
+          scan_pass_mfma<kCompactBlocks, true>(P, cols, 0u, mc, n_in, wl, lane, clk);
+        }
         replay_lists<true, true, true>(P, mc.geom, nullptr, 0, wl, lane, clk, mc.index, mc.count);
         RT_STAMP(clk.replay, clk.t0);
       } else if (!tail) {
