@@ -30,8 +30,11 @@ extern "C" {
 /* 2: rt_render renders exactly the listed tiles (a partial list used to be ignored and the whole
  *    frame rendered); rt_render_multi, rt_accumulate_*, rt_resolve_device_async,
  *    rt_render_rows_device_noalloc, rt_scene_scan_info and RT_FLAG_SCAN_VALU were added; calls
- *    from several host threads are serialised behind one lock.  Nothing was removed. */
-#define RT_ABI_VERSION 2
+ *    from several host threads are serialised behind one lock.  Nothing was removed.
+ * 3: no entry point changed, but a seed gives other frames than before: the draws inside a sample
+ *    come from another recurrence (include/rt_rng.h); the distribution and the order of draws are
+ *    the same. */
+#define RT_ABI_VERSION 3
 
 typedef enum rt_status {
   RT_OK = 0,
