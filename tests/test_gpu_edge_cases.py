@@ -93,3 +93,31 @@ def test_depth_zero_writes_only_the_pixels_its_tiles_cover():
         assert np.all(got[4:8] == 5.0) and np.all(got[12:16] == 5.0)
         assert hip.get_stats().samples == 2 * 4 * w * 4
     scene.close()
+
+
+# Frames so small that the work runs out at once: every wave is draining from its first steps, the
+# live paths of a wave go through the one-pass forms of the matrix filter (up to 16 and up to 64
+# paths) and items lend their last sample to idle path slots.  Items of one, two and nine samples
+# (3, 100 and 500 samples per pixel).  The hierarchy kernel runs one path per lane and lends
+# nothing, so its sliced frame checks the lending kernels bit for bit; the oracle checks them all
+# through the sequential order.
+@pytest.mark.parametrize("w,h,spp", [(64, 36, 3), (48, 27, 100), (16, 9, 500), (5, 3, 100)])
+def test_frames_whose_work_runs_out_at_once(w, h, spp):
+    s, m = O.random_world(1, -11, 11)
+    cam = O.camera_new((13, 2, 3), (0, 0, 0), 20.0, w / h)
+    tiles = O.job_queue(w, h, 64, 64)
+    frames = {}
+    for name, flags in (("matrix", 0), ("vector", abi.RT_FLAG_SCAN_VALU),
+                        ("literal", abi.RT_FLAG_STRICT_FP), ("hierarchy", abi.RT_FLAG_ACCEL)):
+        frames[name] = hip.render_tiles(s, m, cam, w, h, spp, 50, 9, tiles, flags=flags)
+        st = hip.get_stats()
+        frames[name + " rays"] = (st.rays, st.samples, st.slices)
+    assert frames["hierarchy rays"][2] > 1      # sliced: the mode in which samples are lent
+    for name in ("matrix", "vector", "literal"):
+        assert np.array_equal(frames[name].view(np.uint32), frames["hierarchy"].view(np.uint32)), name
+        assert frames[name + " rays"] == frames["hierarchy rays"], name
+    _, _, ctr, ref = O.render(s, m, cam, w, h, spp, 50, 9, mode=O.RO_MODE_ITER_MUL, threads=8,
+                              tiles=tiles, want_sums=True)
+    assert frames["matrix rays"][:2] == (ctr.rays, ctr.samples)
+    ok = ~np.isnan(ref)
+    assert np.allclose(frames["matrix"][ok], ref[ok], rtol=4e-6, atol=2e-5 * max(1, spp // 100))
