@@ -541,6 +541,10 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
   }
   p.width = frame->image_width;
   p.height = frame->image_height;
+  p.fwidth = (float)frame->image_width;
+  p.fheight = (float)frame->image_height;
+  p.inv_width = 1.0f / p.fwidth;
+  p.inv_height = 1.0f / p.fheight;
   p.max_depth = frame->max_depth;
   p.spp = frame->samples_per_pixel;
   p.seed_a = rt_rng_seed_a(frame->seed);

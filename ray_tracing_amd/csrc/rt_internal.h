@@ -125,6 +125,19 @@ __host__ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const Divider&
 #endif
   return (t + ((n - t) >> v.sh1)) >> v.sh2;
 }
+// a / b, correctly rounded, for a divisor whose correctly rounded reciprocal y = 1.0f / b is at
+// hand: five instructions of the fast kind in place of the division's expansion (two scalings,
+// the hardware's reciprocal, six more).  q = a * y is within 1.5 ulp of a / b; one step
+// q += (a - b q) y brings it within an ulp (the residual a - b q then is exact), and the second
+// such step rounds to the nearest (Markstein's theorem).  Holds where nothing overflows or
+// underflows, which a, b of the sample loop (0 or 2^-24 <= a <= 2^31, 1 <= b <= 2^31) cannot.
+__host__ __device__ __forceinline__ float div_by(float a, float b, float y) {
+  float q = a * y;
+  float r = __builtin_fmaf(-b, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, y, q);
+}
 #endif
 
 // One tile of the request as the kernel sees it.
@@ -206,6 +219,9 @@ struct TraceParams {
   rt_camera cam;
   float origin[3];        // view_inv * (0,0,0,1), a per-frame constant (src/main.rs:71-72)
   uint32_t width, height;
+  // `width as f32`, `height as f32` and their reciprocals 1.0f / x (correctly rounded, formed on
+  // the host), for the divisions of src/cpu/job.rs:53-54: see div_by in rt_kernels.hip
+  float fwidth, fheight, inv_width, inv_height;
   uint32_t max_depth, spp;
   uint32_t seed_a;          // rt_rng_seed_a(seed)
   uint32_t slices;          // work items per pixel; item = pixel * slices + slice

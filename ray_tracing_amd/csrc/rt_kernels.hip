@@ -1734,8 +1734,8 @@ template <bool LEAN = false>
 __device__ __forceinline__ void start_sample(Path& P, const TraceParams& p) {
   P.rng.g = rt_rng_from_pixel(P.pixel, P.sample);
   P.rng.draws = 0;
-  float u = (P.fx + next_f32(P.rng)) / (float)p.width;
-  float v = (P.fy + next_f32(P.rng)) / (float)p.height;
+  float u = div_by(P.fx + next_f32(P.rng), p.fwidth, p.inv_width);     // `/ image_width as f32`
+  float v = div_by(P.fy + next_f32(P.rng), p.fheight, p.inv_height);   // `/ image_height as f32`
   u = u * 2.0f - 1.0f;
   v = v * 2.0f - 1.0f;
   const float* PI = p.cam.proj_inv;

@@ -77,3 +77,18 @@ def test_host_prepared_dividers_match_integer_division(tmp_path):
                    check=True, capture_output=True, timeout=300)
     p = subprocess.run([out], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and p.stdout.startswith("ok "), p.stdout + p.stderr
+
+
+def test_division_by_a_prepared_reciprocal_is_the_division(tmp_path):
+    """The sample loop's `(x + jitter) / image_width as f32` (src/cpu/job.rs:53-54) is computed as
+    rt::div_by from the reciprocal prepared on the host; the same inline code, compiled for the
+    host, must give the bits of `/`: every float below the extent for two image extents, sweeps
+    for the others."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = str(tmp_path / "div_by_check")
+    subprocess.run([HIPCC, "-O2", "-std=c++17", "-ffp-contract=off", "-x", "hip", "--offload-arch=gfx950",
+                    os.path.join(ROOT, "tests", "native", "div_by_check.cpp"), "-o", out],
+                   check=True, capture_output=True, timeout=300)
+    p = subprocess.run([out], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and p.stdout.startswith("ok "), p.stdout + p.stderr
