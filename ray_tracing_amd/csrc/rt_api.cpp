@@ -938,6 +938,18 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
     memcpy(&idbits, &s.material_id, sizeof idbits);
     memcpy(&flagbits, &m.flags, sizeof flagbits);
     surf[2 * (size_t)i] = make_float4(m.r, m.g, m.b, flagbits);
+    if (m.flags & RT_MAT_DIELECTRIC) {
+      // A dielectric scatters white (src/main.rs:201-227) and nothing reads its colour: the three
+      // words hold what the branch computes from ir alone, formed here with the same operations:
+      // `1.0 / ir` (src/main.rs:207) and reflectance's r0 (src/main.rs:163-164) for ir and 1 / ir.
+      const auto r0_of = [](float ref_index) {
+        volatile float q = (1.0f - ref_index) / (1.0f + ref_index);
+        volatile float r0 = q * q;
+        return (float)r0;
+      };
+      volatile float inv_ir = 1.0f / m.ir;
+      surf[2 * (size_t)i] = make_float4(inv_ir, r0_of(inv_ir), r0_of(m.ir), flagbits);
+    }
     surf[2 * (size_t)i + 1] = make_float4(m.metallic_strength, m.ir, s.radius, idbits);
   }
   rt_scene* s = new rt_scene();
@@ -1606,6 +1618,21 @@ int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays,
   RT_HIP(rt::launch_hook(hp, (flags & RT_FLAG_STRICT_FP) != 0, ctx().stream));
   RT_HIP(hipStreamSynchronize(ctx().stream));
   RT_HIP(hipMemcpy(out, dout.p, (size_t)n_rays * sizeof(rt_ray_out), hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+int rt_selftest_sqrt(uint64_t* out3) {
+  ApiScope scope;
+  if (int rc = check_ready()) return rc;
+  if (!out3) return fail(RT_ERR_INVALID_ARGUMENT, "out3 is NULL");
+  ScopedDev d;
+  RT_HIP(hipMalloc(&d.p, 3 * sizeof(unsigned long long)));
+  RT_HIP(hipMemsetAsync(d.p, 0, 3 * sizeof(unsigned long long), ctx().stream));
+  RT_HIP(rt::launch_sqrt_check((unsigned long long*)d.p, ctx().stream));
+  RT_HIP(hipStreamSynchronize(ctx().stream));
+  unsigned long long h[3];
+  RT_HIP(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 3; ++i) out3[i] = h[i];
   return RT_OK;
 }
 

@@ -158,7 +158,9 @@ inline void set_tile_width(TileDev& t, uint32_t w) {
 //             |c|^2 - r^2 minus a rounding slack (see trigger_constant in rt_api.cpp)
 //   geom[i] = (cx, cy, cz, radius*radius)       read when a sphere is replayed exactly
 //   surf[2i] = (r, g, b, flags bits), surf[2i+1] = (metallic_strength, ir, radius, material_id
-//             bits): the sphere's radius and a copy of its material, read once per hit
+//             bits): the sphere's radius and a copy of its material, read once per hit; for a
+//             dielectric, whose colour nothing reads, (1/ir, r0 of 1/ir, r0 of ir) instead of
+//             (r, g, b), r0 being reflectance's ((1 - x) / (1 + x))^2
 // Optional bounding-volume hierarchy (RT_FLAG_ACCEL; built by build_bvh in rt_bvh.cpp).
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 struct BvhNode {
@@ -297,5 +299,6 @@ hipError_t launch_zero(const ZeroParams& p, hipStream_t stream);
 hipError_t launch_clear_counters(Counters* c, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream);
 hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream);
+hipError_t launch_sqrt_check(unsigned long long* out3, hipStream_t stream);   // out3 zeroed by the caller
 
 }  // namespace rt

@@ -156,9 +156,44 @@ __device__ __forceinline__ V3 divs(V3 a, float s) { return mk(a.x / s, a.y / s, 
 __device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
 // glam: (x*x') + (y*y') + (z*z'), left to right, no contraction
 __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+// sqrt, correctly rounded, for the hot places: what the compiler makes of sqrtf without its first
+// and last steps.  v_sqrt_f32 is within an ulp of the root, so the root rounded to nearest is that
+// value s or a neighbour, and the signs of x - s- s and x - s+ s (one fused operation each, s-
+// and s+ the neighbours) say which.  The compiler's expansion does the same between a scaling by
+// 2^32 for x < 2^-96, whose residuals would underflow, and a fix-up for 0 and infinity: nine of
+// its fifteen instructions.  Over all 2^32 inputs (tools/ubench/sqrt_exhaustive.hip) the nine
+// give the bits of the fifteen except for 0 < |x| < 2^-96:
+//  - sqrt_1my is for x = 1 - y or |1 - y| of a float y, which is 0, NaN or at least 2^-24 in
+//    magnitude, and for sums of squares of multiples of 2^-23 (0 or at least 2^-46);
+//  - sqrt_rn is for any x: a wave that holds an x inside that gap (or a NaN) takes the compiler's
+//    expansion for all its lanes, and the others never see it.
+#ifndef RT_FAST_SQRT
+#define RT_FAST_SQRT 1
+#endif
+__device__ __forceinline__ float sqrt_1my(float x) {
+  if (!RT_FAST_SQRT) return __builtin_sqrtf(x);
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float below = __uint_as_float(__float_as_uint(s) - 1u);
+  const float above = __uint_as_float(__float_as_uint(s) + 1u);
+  const float r_below = __builtin_fmaf(-below, s, x);
+  const float r_above = __builtin_fmaf(-above, s, x);
+  s = 0.0f >= r_below ? below : s;
+  s = 0.0f < r_above ? above : s;
+  return s;
+}
+__device__ __forceinline__ float sqrt_rn(float x) {
+  float s = sqrt_1my(x);
+  if (RT_FAST_SQRT == 1 && __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(x) >= 0x1p-96f)) != 0) {
+    // (the empty statement keeps the compiler from computing this ahead of the branch, for every
+    // wave: to it, the square root is one cheap operation)
+    asm volatile("" : "+v"(x));
+    s = __builtin_sqrtf(x);
+  }
+  return s;
+}
 // glam: v * (1.0 / sqrt(dot(v, v)))
 __device__ __forceinline__ V3 normalize(V3 a) {
-  float len = __builtin_sqrtf(dot(a, a));
+  float len = sqrt_rn(dot(a, a));
   float rcp = 1.0f / len;
   return scale(a, rcp);
 }
@@ -188,6 +223,13 @@ __device__ __forceinline__ V3 random_vec3(PathRng& r) {
   float z = next_signed(r);
   return mk(x, y, z);
 }
+// normalize of a vector whose components are multiples of 2^-23 (random_vec3's): the sum of
+// their squares is 0 or at least 2^-46
+__device__ __forceinline__ V3 normalize_draw(V3 a) {
+  float len = sqrt_1my(dot(a, a));
+  float rcp = 1.0f / len;
+  return scale(a, rcp);
+}
 // random_in_unit_sphere_vec3, src/main.rs:273-282
 __device__ __forceinline__ V3 random_in_unit_sphere(PathRng& r) {
   for (;;) {
@@ -205,13 +247,13 @@ __device__ __forceinline__ V3 reflect(V3 input, V3 normal) {
 __device__ __forceinline__ V3 refract(V3 uv, V3 n, float etai_over_etat) {
   float cos_theta = __builtin_fminf(dot(neg(uv), n), 1.0f);
   V3 out_perp = scale(add(uv, scale(n, cos_theta)), etai_over_etat);
-  float k = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot(out_perp, out_perp)));
+  float k = -sqrt_1my(__builtin_fabsf(1.0f - dot(out_perp, out_perp)));
   return add(out_perp, scale(n, k));
 }
-// reflectance, src/main.rs:162-166; powf(x, 5.0) as three multiplies (within 2 ulp of libm)
-__device__ __forceinline__ float reflectance(float cosine, float ref_index) {
-  float r0 = (1.0f - ref_index) / (1.0f + ref_index);
-  r0 = r0 * r0;
+// reflectance, src/main.rs:162-166; powf(x, 5.0) as three multiplies (within 2 ulp of libm).
+// r0 = ((1 - ref_index) / (1 + ref_index))^2 comes with the sphere's record: ref_index is the
+// material's ir or 1 / ir, so the host has formed both values, with the same operations.
+__device__ __forceinline__ float reflectance(float cosine, float r0) {
   float x = 1.0f - cosine;
   float x2 = x * x;
   float x4 = x2 * x2;
@@ -222,7 +264,7 @@ __device__ __forceinline__ float reflectance(float cosine, float ref_index) {
 // and the dielectric branch both normalise the ray direction; computing the factor once ahead
 // of them takes the square root and the division out of both.
 __device__ __forceinline__ float inv_length(float a) {
-  return 1.0f / __builtin_sqrtf(a);
+  return 1.0f / sqrt_rn(a);
 }
 // sky, src/main.rs:256-262; inv_len = inv_length(dot(dir, dir))
 __device__ __forceinline__ V3 sky(V3 dir, float inv_len) {
@@ -294,7 +336,7 @@ __device__ __forceinline__ void candidate_hit(float4 s, uint32_t index, V3 o, V3
   const float s_hi = __builtin_amdgcn_sqrtf(discriminant) * 1.00000095367431640625f;
   if ((-half_b - s_hi) * 0.99999904632568359375f > rb.closest_a) return;            // (ii)
   if ((-half_b + s_hi) * 1.00000190734863281250f < rb.tmin_a) return;               // (iii)
-  float sqrtd = __builtin_sqrtf(discriminant);
+  float sqrtd = sqrt_rn(discriminant);
   float root = (-half_b - sqrtd) / a;
   if (root < kTMin) {
     root = (-half_b + sqrtd) / a;
@@ -344,14 +386,17 @@ __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, floa
 
   if (flags & RT_MAT_DIELECTRIC) {                                // src/main.rs:201-227
     b.kind = RT_KIND_DIELECTRIC;
+    // (a dielectric scatters white and its colour is never read, src/main.rs:201-227: its place
+    // in the record holds 1 / ir and the two r0 of reflectance, see upload in rt_api.cpp)
     float ir = m1.y;
-    float ratio = b.front ? 1.0f / ir : ir;
+    float ratio = b.front ? m0.x : ir;        // `if front_face { 1.0 / ir } else { ir }`
+    float r0 = b.front ? m0.y : m0.z;
     V3 u = scale(d, inv_len);   // normalize(d)
     float cos_theta = __builtin_fminf(dot(neg(u), b.normal), 1.0f);
-    float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+    float sin_theta = sqrt_1my(1.0f - cos_theta * cos_theta);
     bool cannot_refract = (ratio * sin_theta) > 1.0f;
     bool do_reflect = cannot_refract;
-    if (!cannot_refract) do_reflect = reflectance(cos_theta, ratio) > next_f32(rng);  // `||`
+    if (!cannot_refract) do_reflect = reflectance(cos_theta, r0) > next_f32(rng);  // `||`
     b.dir = do_reflect ? reflect(u, b.normal) : refract(u, b.normal, ratio);
     b.atten = mk(1.0f, 1.0f, 1.0f);
   } else if (flags & RT_MAT_METALLIC) {                           // src/main.rs:228-242
@@ -367,7 +412,7 @@ __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, floa
     }
   } else {                                                        // src/main.rs:243-251
     b.kind = RT_KIND_DIFFUSE;
-    b.dir = add(b.normal, normalize(ball));
+    b.dir = add(b.normal, normalize_draw(ball));
     b.atten = color;
   }
   return b;
@@ -588,7 +633,7 @@ __device__ __forceinline__ bool candidate_root(float4 s, V3 o, V3 d, float a, fl
   const float s_hi = __builtin_amdgcn_sqrtf(discriminant) * 1.00000095367431640625f;
   if ((-half_b - s_hi) * 0.99999904632568359375f > rb.closest_a) return false;            // (ii)
   if ((-half_b + s_hi) * 1.00000190734863281250f < rb.tmin_a) return false;               // (iii)
-  float sqrtd = __builtin_sqrtf(discriminant);
+  float sqrtd = sqrt_rn(discriminant);
   float root = (-half_b - sqrtd) / a;
   if (root < kTMin) {
     root = (-half_b + sqrtd) / a;
@@ -2637,6 +2682,29 @@ static_assert((size_t)lds_capacity(kChunkSpheres + 1) * (sizeof(float4) + sizeof
                       queue_bytes(kThreads) + 256 <= kLdsPerWorkgroup,
               "two workgroups of the chunked kernel must fit into a CU's LDS");
 
+// Self-test of the short square roots: every one of the 2^32 floats through sqrt_rn and
+// sqrt_1my against the compiler's sqrtf.  out[0] = inputs where sqrt_rn gives other bits,
+// out[1] = inputs outside 0 < |x| < 2^-96 where sqrt_1my does, out[2] = inputs inside that gap
+// where sqrt_1my does (what sqrt_rn's branch is there for; not zero).
+__global__ __launch_bounds__(256) void sqrt_check_kernel(unsigned long long* out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint32_t bad_rn = 0, bad_1my = 0, gap = 0;
+  for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < (1ull << 32); v += stride) {
+    float x = __uint_as_float((uint32_t)v);
+    asm volatile("" : "+v"(x));
+    const uint32_t want = __float_as_uint(__builtin_sqrtf(x));
+    const uint32_t mag = (uint32_t)v & 0x7FFFFFFFu;
+    const bool in_gap = mag != 0u && mag < 0x0F800000u;
+    if (__float_as_uint(sqrt_rn(x)) != want) ++bad_rn;
+    if (__float_as_uint(sqrt_1my(x)) != want) {
+      if (in_gap) ++gap; else ++bad_1my;
+    }
+  }
+  if (bad_rn) atomicAdd(&out[0], (unsigned long long)bad_rn);
+  if (bad_1my) atomicAdd(&out[1], (unsigned long long)bad_1my);
+  if (gap) atomicAdd(&out[2], (unsigned long long)gap);
+}
+
 }  // namespace
 
 size_t trace_lds_bytes(uint32_t n_spheres, bool accel, uint32_t bvh_nodes, uint32_t bvh_depth,
@@ -2753,6 +2821,11 @@ hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream) {
   if (blocks > 8192) blocks = 8192;
   if (blocks == 0) return hipSuccess;
   hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_sqrt_check(unsigned long long* out3, hipStream_t stream) {
+  hipLaunchKernelGGL(sqrt_check_kernel, dim3(4096), dim3(256), 0, stream, out3);
   return hipGetLastError();
 }
 

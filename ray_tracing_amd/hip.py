@@ -25,7 +25,7 @@ EXPORTS = (
     "rt_render_device_async", "rt_render_rows_device_async", "rt_render_rows_device_noalloc",
     "rt_accumulate_device_async", "rt_resolve_device_async",
     "rt_synchronize", "rt_get_stats", "rt_get_launch_ms", "rt_get_phase_cycles", "rt_trace_rays",
-    "rt_scene_scan_info",
+    "rt_scene_scan_info", "rt_selftest_sqrt",
 )
 
 
@@ -93,6 +93,7 @@ def lib():
     L.rt_get_launch_ms.restype = i
     L.rt_get_phase_cycles.argtypes = [vp]
     L.rt_trace_rays.argtypes = [vp, vp, u32, u32, u32, vp]
+    L.rt_selftest_sqrt.argtypes = [vp]
     L.rt_scene_scan_info.argtypes = [vp, C.POINTER(abi.RtScanInfo)]
     _lib = L
     return L
@@ -286,6 +287,14 @@ def get_phase_cycles():
     out = np.zeros(16, dtype=np.uint64)
     check(lib().rt_get_phase_cycles(abi.ptr(out)))
     return out
+
+
+def selftest_sqrt():
+    """(differing inputs of the guarded form, of the unguarded form where it is used, of the
+    unguarded form inside 0 < |x| < 2^-96) over all 2^32 floats; see rt_selftest_sqrt."""
+    out = np.zeros(3, dtype=np.uint64)
+    check(lib().rt_selftest_sqrt(abi.ptr(out)))
+    return tuple(int(v) for v in out)
 
 
 def trace_rays(scene, rays, seed, flags=0):

@@ -445,3 +445,17 @@ def test_one_process_several_devices_gives_the_same_frame():
     # the primary context is back in charge afterwards
     again = hip.render(s, m, cam, w, h, spp, 50, 3)
     assert np.array_equal(np.isnan(one), np.isnan(again))
+
+
+@pytest.mark.gpu
+def test_short_square_roots_give_the_bits_of_sqrtf_on_every_float():
+    """The kernels take the reference's `.sqrt()` (src/main.rs:141, 211, 320 and inside
+    `.normalize()`) through a shorter instruction sequence than the compiler's sqrtf: the
+    hardware's square root, its two neighbours and the signs of their residuals.  All 2^32
+    floats, on the GPU: the guarded form (arbitrary inputs) never differs, the unguarded form
+    differs only for 0 < |x| < 2^-96, which the inputs it is used on (1 - y, |1 - y|, sums of
+    squares of multiples of 2^-23) cannot be."""
+    guarded, unguarded, in_gap = hip.selftest_sqrt()
+    assert guarded == 0
+    assert unguarded == 0
+    assert in_gap > 0   # the gap is real: the guard is not decoration
