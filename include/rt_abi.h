@@ -33,8 +33,9 @@ extern "C" {
  *    from several host threads are serialised behind one lock.  Nothing was removed.
  * 3: no entry point changed, but a seed gives other frames than before: the draws inside a sample
  *    come from another recurrence (include/rt_rng.h); the distribution and the order of draws are
- *    the same. */
-#define RT_ABI_VERSION 3
+ *    the same.
+ * 4: the same again (a linear congruential step inside a sample). */
+#define RT_ABI_VERSION 4
 
 typedef enum rt_status {
   RT_OK = 0,

@@ -9,17 +9,21 @@
  * (seed, pixel index, sample index, draw number).  A render is then bit-reproducible for any
  * tiling, any lane assignment and any number of GPUs.
  *
- * stream(seed, pixel, sample):   state0 = mix(mix(mix(seed ^ A) ^ pixel) + sample)   (never 0)
+ * stream(seed, pixel, sample):   state0 = mix(mix(mix(seed ^ A) ^ pixel) + sample)
  *                                inc    = (state0 rotated right by 11 bits) ^ B | 1
- * draw number c (0-based):       bits = x(c + 1) + inc, with x(0) = state0 and x(k + 1) = the
- *                                xorshift32 step (13, 17, 5) of x(k);  xi = (bits >> 8) * 2^-24
+ * draw number c (0-based):       bits = x(c + 1), with x(0) = state0 and
+ *                                x(k + 1) = x(k) * 747796405 + inc mod 2^32;  xi = (bits >> 8) * 2^-24
  * mix() is the 32-bit finaliser "lowbias32" (two multiplies, three xor-shifts).  It seeds every
- * sample's stream - one hash per pixel and one per sample; the draws inside a sample come from
- * the shift-and-xor recurrence, because a 32-bit integer multiply runs at a quarter of the vector
- * ALU's rate on the GPU and a path makes four draws per segment (one hash per draw, and four
- * per sample: about 2 % of the benchmark frame's time).  Marsaglia's xorshift32 has the full
- * period 2^32 - 1 over non-zero states; `inc` keeps the streams of two samples that meet on that
- * cycle from handing out the same values (their draws differ by a constant modulo 1).
+ * sample's stream - one hash per pixel and one per sample.  The draws inside a sample come from
+ * a linear congruential step, the cheapest recurrence the GPU's vector ALU has (one integer
+ * multiply and one add: a third of the issue time of a shift-and-xor recurrence with three
+ * shifts, a sixth of a hash per draw), because the kernels draw in a rejection loop that a whole
+ * wave repeats until its unluckiest lane is done: 4 % of the benchmark frame's time lay between
+ * this recurrence and the shift-and-xor one.  The multiplier is 1 mod 4 and inc is odd, so every
+ * stream has the full period 2^32 (Hull and Dobell); a draw takes the upper 24 bits of the state,
+ * whose periods are the longest (bit b of such a state repeats after 2^(b+1) steps: 512 for the
+ * lowest bit a draw uses, and a sample draws a few dozen numbers); `inc` keeps two samples
+ * whose states meet from handing out the same values from there on.
  *
  * Scene construction (the reference's create_random_world draws from the same rand::random)
  * uses the counter form: state0 as above, inc = mix(mix(mix(seed + B) + pixel) ^ sample) | 1,
@@ -58,7 +62,6 @@ RT_HD uint32_t rt_rng_pixel(uint32_t seed_a, uint32_t pixel) { return rt_mix32(s
 RT_HD rt_rng rt_rng_from_pixel(uint32_t pixel_hash, uint32_t sample) {
   rt_rng r;
   r.state = rt_mix32(pixel_hash + sample);
-  if (r.state == 0U) r.state = 0x9E3779B9U; /* the one state the shift-and-xor recurrence cannot leave */
   r.inc = (((r.state >> 11) | (r.state << 21)) ^ 0x632BE5ABU) | 1U;
   return r;
 }
@@ -68,12 +71,8 @@ RT_HD rt_rng rt_rng_init(uint32_t seed, uint32_t pixel, uint32_t sample) {
 }
 
 RT_HD uint32_t rt_rng_next_u32(rt_rng* r) {
-  uint32_t x = r->state;
-  x ^= x << 13;
-  x ^= x >> 17;
-  x ^= x << 5;
-  r->state = x;
-  return x + r->inc;
+  r->state = r->state * 747796405U + r->inc;
+  return r->state;
 }
 
 /* Same mapping as rand 0.8.5's Standard distribution for f32: 24 random bits * 2^-24. */

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-RT_ABI_VERSION = 3
+RT_ABI_VERSION = 4
 
 RT_MAT_METALLIC = 1
 RT_MAT_DIELECTRIC = 2

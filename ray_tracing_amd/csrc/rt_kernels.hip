@@ -1185,42 +1185,60 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[NB], 
       const auto entry_offset = [](uint32_t q) {
         return SB == 1 ? q << 4 : ((q >> 3) << 7) | ((q & 7u) << 11);
       };
-      for (;;) {
-        // A lane with candidates reserves its run of the list with one LDS atomic on the list's
-        // length (the order of the entries does not matter to the replay).
-        const uint32_t mine = (uint32_t)__builtin_popcount(cand);
-        uint32_t at = 0;
-        if (mine != 0)
-          at = __hip_atomic_fetch_add(wl.counter, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      // A lane with candidates reserves its run of the list with one LDS atomic on the list's
+      // length (the order of the entries does not matter to the replay).
+      uint32_t mine = (uint32_t)__builtin_popcount(cand);
+      uint32_t at = 0;
+      if (mine != 0)
+        at = __hip_atomic_fetch_add(wl.counter, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #ifdef RT_DIAG_PHASES
-        clk.trig_pairs += mine;   // per lane; summed over the wave at the end
+      clk.trig_pairs += mine;   // per lane; summed over the wave at the end
 #endif
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(at + mine > L) == 0, 1)) {
-          uint32_t* dst = wl.list + at;
-          while (cand != 0) {
-            const uint32_t q = (uint32_t)__builtin_ctz(cand);
-            cand &= cand - 1;
-            *dst++ = base + entry_offset(q);
-          }
-          break;
-        }
-        // The list is full.  Runs that end below its end are written whole, the one that
-        // straddles the end as far as it fits (so every place up to the end holds an entry), the
-        // list is replayed, and what did not fit (still set in `cand`) is reserved again.
-        while (cand != 0 && at < L) {
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(at + mine > L) == 0, 1)) {
+        uint32_t* dst = wl.list + at;
+        while (cand != 0) {
           const uint32_t q = (uint32_t)__builtin_ctz(cand);
           cand &= cand - 1;
-          wl.list[at] = base + entry_offset(q);
-          ++at;
+          *dst++ = base + entry_offset(q);
         }
-        wl.count = L;
-        RT_STAMP(clk.scan, clk.t0);
-        RT_PRIO_REST();
-        replay_lists<true, false, COMPACT>(P, m.geom, nullptr, 0, wl, lane, clk, m.index, m.count);
-        RT_STAMP(clk.replay, clk.t0);
-        RT_PRIO_MFMA();
-        __hip_atomic_store(wl.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (__builtin_amdgcn_ballot_w64(cand != 0) == 0) break;
+      } else {
+        // The list is full (kept apart from the usual case above, which then is straight code
+        // with one loop: no flags and branches of an enclosing loop around it).  Runs that end
+        // below its end are written whole, the one that straddles the end as far as it fits (so
+        // every place up to the end holds an entry), the list is replayed, and what did not fit
+        // (still set in `cand`) is reserved again.
+        for (;;) {
+          while (cand != 0 && at < L) {
+            const uint32_t q = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1;
+            wl.list[at] = base + entry_offset(q);
+            ++at;
+          }
+          wl.count = L;
+          RT_STAMP(clk.scan, clk.t0);
+          RT_PRIO_REST();
+          replay_lists<true, false, COMPACT>(P, m.geom, nullptr, 0, wl, lane, clk, m.index, m.count);
+          RT_STAMP(clk.replay, clk.t0);
+          RT_PRIO_MFMA();
+          __hip_atomic_store(wl.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (__builtin_amdgcn_ballot_w64(cand != 0) == 0) break;
+          mine = (uint32_t)__builtin_popcount(cand);
+          at = 0;
+          if (mine != 0)
+            at = __hip_atomic_fetch_add(wl.counter, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#ifdef RT_DIAG_PHASES
+          clk.trig_pairs += mine;
+#endif
+          if (__builtin_amdgcn_ballot_w64(at + mine > L) == 0) {
+            uint32_t* dst = wl.list + at;
+            while (cand != 0) {
+              const uint32_t q = (uint32_t)__builtin_ctz(cand);
+              cand &= cand - 1;
+              *dst++ = base + entry_offset(q);
+            }
+            break;
+          }
+        }
       }
 #ifdef RT_DIAG_PHASES
       clk.trig_cycles += __builtin_amdgcn_s_memtime() - trig_t0;

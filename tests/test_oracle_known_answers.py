@@ -313,16 +313,13 @@ def test_counter_stream_matches_python_restatement():
     a = mix(seed ^ 0xA511E9B3)
     b = mix((seed + 0x632BE5AB) & 0xFFFFFFFF)
     state = mix((mix(a ^ pixel) + sample) & 0xFFFFFFFF)
-    # a sample's draws: the xorshift32 recurrence (13, 17, 5) from the hashed state, offset by inc
-    assert state != 0
+    # a sample's draws: a linear congruential step from the hashed state, its increment `inc`
     inc = (((state >> 11) | (state << 21)) & 0xFFFFFFFF) ^ 0x632BE5AB | 1
     rng = O.counter_rng(seed, pixel, sample)
     x = state
     for _ in range(16):
-        x ^= (x << 13) & 0xFFFFFFFF
-        x ^= x >> 17
-        x ^= (x << 5) & 0xFFFFFFFF
-        expect = (((x + inc) & 0xFFFFFFFF) >> 8) / 2.0 ** 24
+        x = (x * 747796405 + inc) & 0xFFFFFFFF
+        expect = (x >> 8) / 2.0 ** 24
         assert O.lib().ro_random_f32(C.byref(rng)) == expect
     # scene construction (the stream RT_RNG_SCENE_STREAM): the counter form, one hash per draw
     pixel, sample = 0xFFFFFFF1, 0
@@ -645,3 +642,53 @@ def test_bmp_writer(tmp_path):
     assert raw[54:57] == bytes([0, 127, 255])
     second = raw[54 + 12:]
     assert second[6:9] == bytes([255, 0, 51])
+
+
+def test_sample_streams_are_uniform_in_one_and_three_dimensions():
+    """The draws inside a sample come from a linear congruential step (include/rt_rng.h), chosen
+    for its cost; what the estimator needs from it is what rand's generator gives the reference
+    (src/main.rs:266-282): draws uniform on [0, 1), consecutive draws uncorrelated, consecutive
+    triples uniform in the cube (random_in_unit_sphere_vec3 rejects on them).  Checked here over
+    the streams of 40 000 (pixel, sample) pairs, 48 draws each, restated in numpy."""
+    def mix(x):
+        x = x ^ (x >> np.uint64(16))
+        x = (x * np.uint64(0x7FEB352D)) & M
+        x = x ^ (x >> np.uint64(15))
+        x = (x * np.uint64(0x846CA68B)) & M
+        return x ^ (x >> np.uint64(16))
+    M = np.uint64(0xFFFFFFFF)
+    seed = 1
+    a = mix(np.array([seed ^ 0xA511E9B3], dtype=np.uint64))[0]
+    pixel = np.repeat(np.arange(400, dtype=np.uint64) * np.uint64(5197) + np.uint64(11), 100)
+    sample = np.tile(np.arange(100, dtype=np.uint64), 400)
+    state = mix((mix(a ^ pixel) + sample) & M)
+    inc = ((((state >> np.uint64(11)) | (state << np.uint64(21))) & M) ^ np.uint64(0x632BE5AB)) | np.uint64(1)
+    # the first stream against the oracle's own generator
+    rng = O.counter_rng(seed, int(pixel[0]), int(sample[0]))
+    x = state.copy()
+    draws = np.empty((48, len(x)))
+    for k in range(48):
+        x = (x * np.uint64(747796405) + inc) & M
+        draws[k] = (x >> np.uint64(8)).astype(np.float64) / 2.0 ** 24
+        assert O.lib().ro_random_f32(C.byref(rng)) == draws[k, 0]
+    n = draws.shape[1]
+    # every draw position: mean 1/2, variance 1/12 (standard errors 0.0014 and 0.0004)
+    assert np.abs(draws.mean(axis=1) - 0.5).max() < 0.007
+    assert np.abs(draws.var(axis=1) - 1 / 12).max() < 0.002
+    # consecutive draws, and draws three apart (the same coordinate of consecutive triples)
+    for lag in (1, 2, 3):
+        c = [np.corrcoef(draws[k], draws[k + lag])[0, 1] for k in range(48 - lag)]
+        assert np.abs(c).max() < 5.0 / np.sqrt(n)
+    # triples (draws 3t, 3t+1, 3t+2) in an 8 x 8 x 8 grid of cells: chi-square with 511 degrees
+    # of freedom (mean 511, standard deviation 32) for every t and for all triples together
+    cells = (np.floor(draws * 8).astype(np.int64)).reshape(16, 3, n)
+    idx = cells[:, 0] * 64 + cells[:, 1] * 8 + cells[:, 2]
+    for t in range(16):
+        counts = np.bincount(idx[t], minlength=512)
+        assert ((counts - n / 512) ** 2 / (n / 512)).sum() < 511 + 5 * 32
+    counts = np.bincount(idx.ravel(), minlength=512)
+    assert ((counts - 16 * n / 512) ** 2 / (16 * n / 512)).sum() < 511 + 5 * 32
+    # the rejection test accepts pi / 6 of the triples
+    v = draws.reshape(16, 3, n) * 2 - 1
+    accept = ((v ** 2).sum(axis=1) < 1).mean()
+    assert abs(accept - np.pi / 6) < 4 * np.sqrt(0.25 / (16 * n))

@@ -129,6 +129,14 @@ struct Stamp { unsigned long long cycles, ticks; };
 #define B_sub_f32_lit(i) asm volatile("v_subrev_f32 %0, 1.0, %0" : "+v"(x[i]))
 #define B_dpp(i) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x[i]))
 
+#define B_fma_smov(i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_mov_b64 vcc, 0" : "+v"(x[i]) : "v"(y), "v"(z) : "vcc")
+#define B_fma_br_not(i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_mov_b64 vcc, 0\n\ts_cbranch_vccnz .Lbn%=\n.Lbn%=:" : "+v"(x[i]) : "v"(y), "v"(z) : "vcc")
+#define B_fma_br_taken(i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_mov_b64 vcc, 0\n\ts_cbranch_vccz .Lbt%=\n\ts_nop 0\n.Lbt%=:" : "+v"(x[i]) : "v"(y), "v"(z) : "vcc")
+#define B_fma_br_execz(i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_cbranch_execz .Lbe%=\n.Lbe%=:" : "+v"(x[i]) : "v"(y), "v"(z))
+#define B_fma_saveexec(i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_mov_b64 vcc, exec\n\ts_and_saveexec_b64 s[22:23], vcc\n\ts_mov_b64 exec, s[22:23]" : "+v"(x[i]) : "v"(y), "v"(z) : "vcc", "s22", "s23", "scc")
+#define B_fma_nop(i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_nop 0" : "+v"(x[i]) : "v"(y), "v"(z))
+#define B_fma_waitcnt(i) asm volatile("v_fma_f32 %0, %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "+v"(x[i]) : "v"(y), "v"(z))
+
 #define LIST(X) X(fma) X(fmac) X(mul_f32) X(add_f32) X(sub_f32) X(max_f32) X(max3_f32) X(max_i32) X(max3_i32) X(min3_u32) \
   X(add_u32) X(xor) X(and) X(or3) X(lshl) X(lshr) X(lshl_add) X(alignbit) X(bitop3) X(cndmask) X(mov) \
   X(mul_lo) X(mul_hi) X(mul_u24) X(mad_u24) X(cvt_f32_u32) X(cvt_pkrtz) X(rcp) X(sqrt) X(rsq) \
@@ -136,7 +144,7 @@ struct Stamp { unsigned long long cycles, ticks; };
   X(or) X(sub_u32) X(add3) X(xad) X(and_or) X(lshl_or) X(add_lshl) X(lshl1) X(lshlv) X(lshrv) X(ashr) X(not) X(bfe) X(bfi) \
   X(min_f32) X(med3_f32) X(cndmask_s) X(cvt_u32_f32) X(cvt_f32_f16) X(cvt_f16_f32) X(fmamk) X(fmaak) X(mul_lit) X(mul_sgpr) \
   X(add_sgpr) X(fma_neg) X(add_abs) X(fract) X(floor) X(ldexp) X(exp) X(cmp_sgpr) X(readfirst) X(and3) X(mul_i32_i24) X(sad) \
-  X(add_co) X(sub_f32_lit)
+  X(add_co) X(sub_f32_lit) X(fma_smov) X(fma_br_not) X(fma_br_taken) X(fma_br_execz) X(fma_saveexec) X(fma_nop) X(fma_waitcnt)
 
 #define DEF(n) DEFINE_KERNEL(n, B_##n)
 LIST(DEF)
