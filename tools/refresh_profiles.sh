@@ -3,6 +3,8 @@
 # the four configurations (bench line, kernel trace, PMC passes), a rank's shares, the drain's
 # probes and wave log, the CPU port table, all configurations.  Results go to gpurun_out/refresh_*;
 # tools/refresh_profiles_collect.sh (run in the build container) condenses them into profiles/round3.
+# Before the call, remove gpurun_out/refresh_* in the build container: what an earlier run left there
+# would be condensed together with the new results.
 # Usage (GPU box): bash tools/refresh_profiles.sh [part]     part: a (profiles), b (the rest); default both
 set -o pipefail
 export TMPDIR=/tmp
