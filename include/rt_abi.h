@@ -349,13 +349,15 @@ int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays,
 
 /* Self-test of the kernels' square roots.  Where the reference takes a square root (`.sqrt()`,
  * src/main.rs:141, 211, 320, and inside `.normalize()`, src/main.rs:80, 209, 256, 285; correctly
- * rounded), the kernels' hot places use a shorter instruction
- * sequence than the compiler's sqrtf; this runs every one of the 2^32 floats through both on the
- * GPU and counts the inputs whose results differ in any bit: out3[0] for the guarded form used
- * on arbitrary inputs (must be 0), out3[1] for the unguarded form on the inputs it is used for
- * (everything but 0 < |x| < 2^-96; must be 0), out3[2] for the unguarded form inside that gap
- * (what the guard is for; not 0).  Takes about a second.  No counterpart in the reference. */
-int rt_selftest_sqrt(uint64_t* out3);
+ * rounded, and in normalize followed by the correctly rounded `1.0 / length`), the kernels' hot
+ * places use shorter instruction sequences than the compiler's sqrtf and division; this runs
+ * every one of the 2^32 floats through both on the GPU and counts the inputs whose results differ
+ * in any bit: out4[0] for the guarded square root used on arbitrary inputs (must be 0), out4[1]
+ * for the unguarded form on the inputs it is used for (everything but 0 < |x| < 2^-96; must be
+ * 0), out4[2] for the unguarded form inside that gap (what the guard is for; not 0), out4[3] for
+ * 1 / sqrt(x) as normalize takes it (must be 0).  Takes about a second.  No counterpart in the
+ * reference. */
+int rt_selftest_sqrt(uint64_t* out4);
 
 #ifdef __cplusplus
 }

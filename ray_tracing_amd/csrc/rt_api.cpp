@@ -538,6 +538,11 @@ int render_tiles_device(const rt_scene* scene, const rt_frame* frame, const rt::
     r = r + V[8 + i] * 0.0f;
     r = r + V[12 + i] * 1.0f;
     p.origin[i] = r;
+    const float* PI = frame->camera.proj_inv;
+    volatile float z0 = PI[8 + i] * 0.0f, w1 = PI[12 + i] * 1.0f, w0 = V[12 + i] * 0.0f;
+    p.proj_z0[i] = z0;
+    p.proj_w1[i] = w1;
+    p.view_w0[i] = w0;
   }
   p.width = frame->image_width;
   p.height = frame->image_height;
@@ -951,6 +956,14 @@ int rt_scene_create(const rt_sphere* spheres, uint32_t n_spheres, const rt_mater
       surf[2 * (size_t)i] = make_float4(inv_ir, r0_of(inv_ir), r0_of(m.ir), flagbits);
     }
     surf[2 * (size_t)i + 1] = make_float4(m.metallic_strength, m.ir, s.radius, idbits);
+    if ((m.flags & RT_MAT_METALLIC) && !(m.flags & RT_MAT_DIELECTRIC)) {
+      // A metal's attenuation is its colour applied twice and its fuzz 1 - metallic_strength
+      // (src/main.rs:199, 230, 236-242): the products and the difference, formed here with the
+      // same operations, take the colour's and the strength's places.
+      volatile float rr = m.r * m.r, gg = m.g * m.g, bb = m.b * m.b, fuzz = 1.0f - m.metallic_strength;
+      surf[2 * (size_t)i] = make_float4(rr, gg, bb, flagbits);
+      surf[2 * (size_t)i + 1] = make_float4(fuzz, m.ir, s.radius, idbits);
+    }
   }
   rt_scene* s = new rt_scene();
   s->device = ctx().device;
@@ -1621,18 +1634,18 @@ int rt_trace_rays(const rt_scene* scene, const rt_ray_in* rays, uint32_t n_rays,
   return RT_OK;
 }
 
-int rt_selftest_sqrt(uint64_t* out3) {
+int rt_selftest_sqrt(uint64_t* out4) {
   ApiScope scope;
   if (int rc = check_ready()) return rc;
-  if (!out3) return fail(RT_ERR_INVALID_ARGUMENT, "out3 is NULL");
+  if (!out4) return fail(RT_ERR_INVALID_ARGUMENT, "out4 is NULL");
   ScopedDev d;
-  RT_HIP(hipMalloc(&d.p, 3 * sizeof(unsigned long long)));
-  RT_HIP(hipMemsetAsync(d.p, 0, 3 * sizeof(unsigned long long), ctx().stream));
+  RT_HIP(hipMalloc(&d.p, 4 * sizeof(unsigned long long)));
+  RT_HIP(hipMemsetAsync(d.p, 0, 4 * sizeof(unsigned long long), ctx().stream));
   RT_HIP(rt::launch_sqrt_check((unsigned long long*)d.p, ctx().stream));
   RT_HIP(hipStreamSynchronize(ctx().stream));
-  unsigned long long h[3];
+  unsigned long long h[4];
   RT_HIP(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 3; ++i) out3[i] = h[i];
+  for (int i = 0; i < 4; ++i) out4[i] = h[i];
   return RT_OK;
 }
 

@@ -160,7 +160,8 @@ inline void set_tile_width(TileDev& t, uint32_t w) {
 //   surf[2i] = (r, g, b, flags bits), surf[2i+1] = (metallic_strength, ir, radius, material_id
 //             bits): the sphere's radius and a copy of its material, read once per hit; for a
 //             dielectric, whose colour nothing reads, (1/ir, r0 of 1/ir, r0 of ir) instead of
-//             (r, g, b), r0 being reflectance's ((1 - x) / (1 + x))^2
+//             (r, g, b), r0 being reflectance's ((1 - x) / (1 + x))^2; for a metal (r*r, g*g, b*b)
+//             and 1 - metallic_strength instead of (r, g, b) and metallic_strength
 // Optional bounding-volume hierarchy (RT_FLAG_ACCEL; built by build_bvh in rt_bvh.cpp).
 constexpr uint32_t kBvhLeaf = 0x80000000u;
 struct BvhNode {
@@ -220,6 +221,10 @@ struct TraceParams {
   SceneDev scene;
   rt_camera cam;
   float origin[3];        // view_inv * (0,0,0,1), a per-frame constant (src/main.rs:71-72)
+  // Terms of Camera::get_ray's two Mat4 * Vec4 products that do not depend on the sample
+  // (src/main.rs:74-78: the point's z = 0 and w = 1, the direction's w = 0), formed on the host:
+  // proj_inv's column 2 times 0.0, its column 3 times 1.0, view_inv's column 3 times 0.0
+  float proj_z0[3], proj_w1[3], view_w0[3];
   uint32_t width, height;
   // `width as f32`, `height as f32` and their reciprocals 1.0f / x (correctly rounded, formed on
   // the host), for the divisions of src/cpu/job.rs:53-54: see div_by in rt_kernels.hip
@@ -299,6 +304,6 @@ hipError_t launch_zero(const ZeroParams& p, hipStream_t stream);
 hipError_t launch_clear_counters(Counters* c, hipStream_t stream);
 hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream);
 hipError_t launch_hook(const HookParams& p, bool strict, hipStream_t stream);
-hipError_t launch_sqrt_check(unsigned long long* out3, hipStream_t stream);   // out3 zeroed by the caller
+hipError_t launch_sqrt_check(unsigned long long* out4, hipStream_t stream);   // out4 zeroed by the caller
 
 }  // namespace rt

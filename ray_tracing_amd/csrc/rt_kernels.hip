@@ -191,11 +191,29 @@ __device__ __forceinline__ float sqrt_rn(float x) {
   }
   return s;
 }
+// 1.0f / sqrt(x), both correctly rounded, as glam's normalize takes them.  For x from 2^-96 up to
+// the largest float the root s lies in [2^-48, 2^64), where the compiler's expansion of 1.0f / s
+// scales nothing and fixes nothing up: it is the hardware's reciprocal and the seven fused
+// operations below (the eleven instructions without v_div_scale_f32 twice, and with plain fused
+// operations for v_div_fmas_f32 and v_div_fixup_f32).  A wave that holds any other x takes the
+// compiler's expansions.  The same bits for every float: rt_selftest_sqrt.
+__device__ __forceinline__ float inv_sqrt_rn(float x) {
+  if (RT_FAST_SQRT != 1) return 1.0f / sqrt_rn(x);
+  const float s = sqrt_1my(x);
+  float y = __builtin_amdgcn_rcpf(s);
+  y = __builtin_fmaf(__builtin_fmaf(-s, y, 1.0f), y, y);
+  float q = y;   // 1.0f * y
+  q = __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), y, q);
+  q = __builtin_fmaf(__builtin_fmaf(-s, q, 1.0f), y, q);
+  if (__builtin_amdgcn_ballot_w64(__float_as_uint(x) - 0x0F800000u >= 0x70000000u) != 0) {
+    asm volatile("" : "+v"(x));
+    q = 1.0f / __builtin_sqrtf(x);
+  }
+  return q;
+}
 // glam: v * (1.0 / sqrt(dot(v, v)))
 __device__ __forceinline__ V3 normalize(V3 a) {
-  float len = sqrt_rn(dot(a, a));
-  float rcp = 1.0f / len;
-  return scale(a, rcp);
+  return scale(a, inv_sqrt_rn(dot(a, a)));
 }
 
 // The random stream of one path.  `draws` is only read by the per-ray test hook.
@@ -264,7 +282,7 @@ __device__ __forceinline__ float reflectance(float cosine, float r0) {
 // and the dielectric branch both normalise the ray direction; computing the factor once ahead
 // of them takes the square root and the division out of both.
 __device__ __forceinline__ float inv_length(float a) {
-  return 1.0f / sqrt_rn(a);
+  return inv_sqrt_rn(a);
 }
 // sky, src/main.rs:256-262; inv_len = inv_length(dot(dir, dir))
 __device__ __forceinline__ V3 sky(V3 dir, float inv_len) {
@@ -402,10 +420,10 @@ __device__ __forceinline__ Bounce shade_hit(const SceneDev& sc, V3 o, V3 d, floa
   } else if (flags & RT_MAT_METALLIC) {                           // src/main.rs:228-242
     b.kind = RT_KIND_METAL;
     V3 reflected = reflect(d, b.normal);
-    float fuzz = 1.0f - m1.x;
+    float fuzz = m1.x;   // `1.0 - metallic_strength`, formed on the host (upload in rt_api.cpp)
     b.dir = add(reflected, scale(ball, fuzz));
     if (dot(reflected, b.normal) > 0.0f) {
-      b.atten = mul(color, color);   // albedo applied twice, src/main.rs:199,236-237,242
+      b.atten = color;   // albedo applied twice, src/main.rs:199,236-237,242: the host's products
     } else {
       b.atten = mk(0.0f, 0.0f, 0.0f);
       b.scattered = false;
@@ -1175,11 +1193,8 @@ __device__ __forceinline__ void scan_pass_mfma(Path (&P)[R], const h8 (&b)[NB], 
         neg = (neg << 8) | ni;
       }
       uint32_t cand = ~neg & 0x0F0F0F0Fu;
-      // (the lane's own part of an entry is formed here, from a lane number the compiler cannot
-      // move out of the loop: a register less to keep across the pass)
-      uint32_t zero = 0;
-      asm volatile("" : "+v"(zero));
-      const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+      // (the lane's own part of an entry: the compiler keeps it in a register across the pass)
+      const uint32_t ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       const uint32_t base = (blk << 7) | (half << 6) | ((ln >> 4) << 9) | (ln & 15u);
       // bit 8 i + j of the mask: sphere + i, and ray block j (16 path slots) or sphere block j
       const auto entry_offset = [](uint32_t q) {
@@ -1806,10 +1821,10 @@ __device__ __forceinline__ void start_sample(Path& P, const TraceParams& p) {
   float d4[3], w[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
-    d4[i] = ((PI[i] * u + PI[4 + i] * v) + PI[8 + i] * 0.0f) + PI[12 + i] * 1.0f;
+    d4[i] = ((PI[i] * u + PI[4 + i] * v) + p.proj_z0[i]) + p.proj_w1[i];   // + c2 * 0.0 + c3 * 1.0
 #pragma unroll
   for (int i = 0; i < 3; ++i)
-    w[i] = ((VI[i] * d4[0] + VI[4 + i] * d4[1]) + VI[8 + i] * d4[2]) + VI[12 + i] * 0.0f;
+    w[i] = ((VI[i] * d4[0] + VI[4 + i] * d4[1]) + VI[8 + i] * d4[2]) + p.view_w0[i];   // + c3 * 0.0
   const V3 dir = normalize(mk(w[0], w[1], w[2]));
   P.ox = p.origin[0]; P.oy = p.origin[1]; P.oz = p.origin[2];
   P.dx = dir.x; P.dy = dir.y; P.dz = dir.z;
@@ -2703,10 +2718,11 @@ static_assert((size_t)lds_capacity(kChunkSpheres + 1) * (sizeof(float4) + sizeof
 // Self-test of the short square roots: every one of the 2^32 floats through sqrt_rn and
 // sqrt_1my against the compiler's sqrtf.  out[0] = inputs where sqrt_rn gives other bits,
 // out[1] = inputs outside 0 < |x| < 2^-96 where sqrt_1my does, out[2] = inputs inside that gap
-// where sqrt_1my does (what sqrt_rn's branch is there for; not zero).
+// where sqrt_1my does (what sqrt_rn's branch is there for; not zero), out[3] = inputs where
+// inv_sqrt_rn gives other bits than 1.0f / sqrtf.
 __global__ __launch_bounds__(256) void sqrt_check_kernel(unsigned long long* out) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  uint32_t bad_rn = 0, bad_1my = 0, gap = 0;
+  uint32_t bad_rn = 0, bad_1my = 0, gap = 0, bad_inv = 0;
   for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < (1ull << 32); v += stride) {
     float x = __uint_as_float((uint32_t)v);
     asm volatile("" : "+v"(x));
@@ -2717,7 +2733,10 @@ __global__ __launch_bounds__(256) void sqrt_check_kernel(unsigned long long* out
     if (__float_as_uint(sqrt_1my(x)) != want) {
       if (in_gap) ++gap; else ++bad_1my;
     }
+    const uint32_t want_inv = __float_as_uint(1.0f / __builtin_sqrtf(x));
+    if (__float_as_uint(inv_sqrt_rn(x)) != want_inv) ++bad_inv;
   }
+  if (bad_inv) atomicAdd(&out[3], (unsigned long long)bad_inv);
   if (bad_rn) atomicAdd(&out[0], (unsigned long long)bad_rn);
   if (bad_1my) atomicAdd(&out[1], (unsigned long long)bad_1my);
   if (gap) atomicAdd(&out[2], (unsigned long long)gap);
@@ -2842,8 +2861,8 @@ hipError_t launch_resolve(const ResolveParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_sqrt_check(unsigned long long* out3, hipStream_t stream) {
-  hipLaunchKernelGGL(sqrt_check_kernel, dim3(4096), dim3(256), 0, stream, out3);
+hipError_t launch_sqrt_check(unsigned long long* out4, hipStream_t stream) {
+  hipLaunchKernelGGL(sqrt_check_kernel, dim3(4096), dim3(256), 0, stream, out4);
   return hipGetLastError();
 }
 

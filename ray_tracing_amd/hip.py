@@ -290,9 +290,10 @@ def get_phase_cycles():
 
 
 def selftest_sqrt():
-    """(differing inputs of the guarded form, of the unguarded form where it is used, of the
-    unguarded form inside 0 < |x| < 2^-96) over all 2^32 floats; see rt_selftest_sqrt."""
-    out = np.zeros(3, dtype=np.uint64)
+    """(differing inputs of the guarded square root, of the unguarded one where it is used, of the
+    unguarded one inside 0 < |x| < 2^-96, of 1 / sqrt(x)) over all 2^32 floats; see
+    rt_selftest_sqrt."""
+    out = np.zeros(4, dtype=np.uint64)
     check(lib().rt_selftest_sqrt(abi.ptr(out)))
     return tuple(int(v) for v in out)
 

@@ -455,7 +455,8 @@ def test_short_square_roots_give_the_bits_of_sqrtf_on_every_float():
     floats, on the GPU: the guarded form (arbitrary inputs) never differs, the unguarded form
     differs only for 0 < |x| < 2^-96, which the inputs it is used on (1 - y, |1 - y|, sums of
     squares of multiples of 2^-23) cannot be."""
-    guarded, unguarded, in_gap = hip.selftest_sqrt()
+    guarded, unguarded, in_gap, inverse = hip.selftest_sqrt()
     assert guarded == 0
     assert unguarded == 0
     assert in_gap > 0   # the gap is real: the guard is not decoration
+    assert inverse == 0   # 1.0 / sqrt(x) of normalize: reciprocal and seven fused operations
