@@ -141,3 +141,44 @@ def test_image_sums_on_a_random_overlapping_scene(flags):
     st = hip.get_stats()
     assert st.rays == ctr.rays and st.samples == ctr.samples
     assert ctr.rays > 3 * ctr.samples      # paths do bounce around in there
+
+
+def test_materials_whose_constants_the_host_prepares():
+    """The library forms a dielectric's 1/ir and reflectance's r0, a metal's colour squared and its
+    fuzz on the host and stores them in the sphere's record (src/main.rs:199-242 computes them per
+    hit).  Materials at the edges of that - both flags set (dielectric wins, src/main.rs:201),
+    ir of 1, below 1, zero, negative and huge, metallic_strength outside [0, 1], colours that are
+    negative or above 1 (create_random_world draws them from [-0.9, 0.9), src/main.rs:349-358) -
+    must still scatter with the oracle's bits, whichever filter runs."""
+    rs = np.random.default_rng(77)
+    mats = [
+        (0.3, 0.6, 0.9, 1, 0.25, 1, 1.5),      # both flags
+        (0.3, 0.6, 0.9, 0, 0.0, 1, 1.0),       # ir 1: r0 = 0
+        (0.3, 0.6, 0.9, 0, 0.0, 1, 0.66),      # ir below 1
+        (0.3, 0.6, 0.9, 0, 0.0, 1, 0.0),       # 1 / ir infinite
+        (0.3, 0.6, 0.9, 0, 0.0, 1, -1.5),      # negative ir: 1 + ir negative
+        (0.3, 0.6, 0.9, 0, 0.0, 1, -1.0),      # r0's division by zero
+        (0.3, 0.6, 0.9, 0, 0.0, 1, 3.0e38),    # 1 + ir rounds, 1 / ir denormal
+        (0.9, -0.9, 1.7, 1, 0.0, 0, 1.5),      # metal: fuzz 1, colours squared
+        (0.2, 0.4, 0.8, 1, 1.0, 0, 1.5),       # metal: fuzz 0
+        (0.2, 0.4, 0.8, 1, 1.75, 0, 1.5),      # metal: fuzz negative
+        (0.2, 0.4, 0.8, 1, -0.5, 0, 1.5),      # metal: fuzz above 1
+        (-0.9, 0.0, 0.89, 0, 0.3, 0, 1.5),     # diffuse with a negative colour
+    ]
+    m = O.materials_array(mats)
+    n = 240
+    c = rs.uniform(-6, 6, size=(n, 3))
+    r = rs.uniform(0.2, 1.2, size=n)
+    s = O.spheres_array([(c[i, 0], c[i, 1], c[i, 2], r[i], i % len(mats)) for i in range(n)])
+    rays = adversarial_rays(rs, s, 2500)
+    scene = hip.Scene(s, m)
+    strict = hip.trace_rays(scene, rays, seed=11, flags=STRICT)
+    assert_same(hip.trace_rays(scene, rays, seed=11, flags=0), strict)
+    assert_same(hip.trace_rays(scene, rays, seed=11, flags=ACCEL), strict)
+    scene.close()
+    ref = O.bounce(O.make_world(s, m), rays, seed=11, pow5_mode=O.RO_POW5_MUL)
+    assert_same(strict, ref, nan_equal=True)
+    # every material was hit, from outside and from inside
+    hit = strict["hit"] == 1
+    assert set(np.unique(strict["material"][hit])) == set(range(len(mats)))
+    assert (strict["front_face"][hit] == 0).sum() > 100
